@@ -1,0 +1,189 @@
+/* pslfe — MI355X-native per-frame feature front-end for PSL-SLAM: the C ABI.
+ *
+ * This is the drop-in boundary.  The reference has no FFI: its seams are plain
+ * C++ calls on objects owned by Tracking (ORBextractor::operator(), LINEextractor::operator(),
+ * CPartiallyRecoverConnectivity, ORBmatcher / LSDmatcher methods).  Each entry point below names
+ * the reference interface it replaces (file:line under the reference tree).  A C++ shim that
+ * mirrors those classes over this ABI is in psl-slam_amd/host/pslfe.hpp; the patch a PSL-SLAM
+ * maintainer applies is in INTEGRATION.md.
+ *
+ * Conventions: plain pointers and sizes only; every function returns PSLFE_OK (0) or a negative
+ * PSLFE_E_* code and never throws; the caller allocates outputs with a capacity and the callee
+ * reports counts; structs are POD with the exact layout of the OpenCV types the reference uses
+ * (cv::KeyPoint 28 B, line_descriptor::KeyLine 68 B); one context per GPU; calls on one handle are
+ * serialised by the caller (the reference has a single Tracking thread), different handles may be
+ * used from different threads.  "d_" arguments are device (HBM) pointers, all others are host.
+ * The library needs a gfx950 GPU: there is no CPU fallback, ctx creation fails without one.
+ */
+#ifndef PSLFE_H
+#define PSLFE_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PSLFE_OK 0
+#define PSLFE_E_INVALID (-1)   /* bad argument (null, size, unsupported configuration)        */
+#define PSLFE_E_NODEVICE (-2)  /* no usable gfx950 device / HIP runtime error at start-up     */
+#define PSLFE_E_HIP (-3)       /* HIP runtime error; text in pslfe_last_error()               */
+#define PSLFE_E_CAPACITY (-4)  /* caller-provided capacity too small                          */
+#define PSLFE_E_STATE (-5)     /* call order (e.g. fetch before extract)                      */
+
+#define PSLFE_MAX_LEVELS 16
+
+/* == cv::KeyPoint as filled by ORBextractor (src/ORBextractor.cc:837-847, 1095-1103). */
+typedef struct PslKeyPoint {
+    float x, y;      /* pt, level-0 pixel coordinates (pt *= mvScaleFactor[octave])            */
+    float size;      /* (int)(31 * mvScaleFactor[octave])                                      */
+    float angle;     /* IC_Angle, degrees in [0,360)                                            */
+    float response;  /* FAST corner score (not Harris: include/ORBextractor.h:49 is unused)    */
+    int32_t octave;
+    int32_t class_id; /* -1 */
+} PslKeyPoint;
+
+/* == cv::line_descriptor::KeyLine, field order of
+ * Thirdparty/line_descriptor/include/line_descriptor/descriptor_custom.hpp:107-146. */
+typedef struct PslKeyLine {
+    float angle;
+    int32_t class_id;
+    int32_t octave;
+    float pt_x, pt_y;
+    float response;
+    float size;
+    float startPointX, startPointY, endPointX, endPointY;
+    float sPointInOctaveX, sPointInOctaveY, ePointInOctaveX, ePointInOctaveY;
+    float lineLength;
+    int32_t numOfPixels;
+} PslKeyLine;
+
+typedef struct pslfe_ctx pslfe_ctx;   /* one per GPU                                           */
+typedef struct pslfe_orb pslfe_orb;   /* == ORBextractor object                                 */
+
+const char* pslfe_version(void);
+/* Last error text of this thread (empty string if none). */
+const char* pslfe_last_error(void);
+
+/* ---- context ------------------------------------------------------------------------------- */
+int pslfe_ctx_create(int device, pslfe_ctx** out);
+void pslfe_ctx_destroy(pslfe_ctx* ctx);
+/* Run all work of this context on an existing HIP stream (hipStream_t passed as void*), e.g. the
+ * caller framework's current stream; NULL = the context's own stream. */
+int pslfe_ctx_set_stream(pslfe_ctx* ctx, void* hip_stream);
+int pslfe_ctx_synchronize(pslfe_ctx* ctx);
+/* Per-stage device timing with HIP events on the launch stream (for bench/roofline).
+ * enable != 0 starts collecting; pslfe_ctx_stage_time returns accumulated milliseconds and the
+ * number of launches of a stage name ("orb.pyramid", "orb.fast", "orb.octree", "orb.blur",
+ * "orb.describe", "match.window", "match.knn2", ...) and resets nothing. */
+int pslfe_ctx_profile(pslfe_ctx* ctx, int enable);
+int pslfe_ctx_profile_reset(pslfe_ctx* ctx);
+int pslfe_ctx_stage_time(pslfe_ctx* ctx, const char* stage, double* ms_total, int* launches);
+
+/* ---- ORB extractor -------------------------------------------------------------------------- */
+/* == ORBextractor::ORBextractor(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST)
+ *    src/ORBextractor.cc:410-470; object created once in Tracking (src/Tracking.cc:120).
+ *    max_batch = most frames one batched call will carry (>=1). */
+int pslfe_orb_create(pslfe_ctx* ctx, int nfeatures, float scaleFactor, int nlevels, int iniThFAST,
+                     int minThFAST, int max_batch, pslfe_orb** out);
+void pslfe_orb_destroy(pslfe_orb* orb);
+
+/* == GetLevels/GetScaleFactor/GetScaleFactors/GetInverseScaleFactors/GetScaleSigmaSquares/
+ *    GetInverseScaleSigmaSquares, include/ORBextractor.h:63-84 (read by Frame ctor src/Frame.cc:141-148).
+ *    Arrays hold nlevels floats. */
+int pslfe_orb_levels(const pslfe_orb* orb);
+float pslfe_orb_scale_factor(const pslfe_orb* orb);
+int pslfe_orb_scale_factors(const pslfe_orb* orb, float* scale, float* inv_scale, float* sigma2,
+                            float* inv_sigma2);
+/* mnFeaturesPerLevel (src/ORBextractor.cc:435-446), nlevels ints. */
+int pslfe_orb_features_per_level(const pslfe_orb* orb, int* quota);
+/* Upper bound on keypoints one frame can return for a w x h image (quota + octree overshoot). */
+int pslfe_orb_max_keypoints(pslfe_orb* orb, int w, int h);
+
+/* == ORBextractor::operator()(image, mask, keypoints, descriptors)
+ *    include/ORBextractor.h:59-61, src/ORBextractor.cc:1043-1105; called from Frame::ExtractORB
+ *    src/Frame.cc:311-317.  One 8UC1 host image in, host outputs; synchronous.
+ *    gray==NULL or w/h<=0 -> PSLFE_OK with *n = 0 (reference returns silently, :1046).
+ *    desc: n x 32 bytes row-major.  cap = capacity of kps/desc in keypoints. */
+int pslfe_orb_extract(pslfe_orb* orb, const uint8_t* gray, int w, int h, int stride,
+                      PslKeyPoint* kps, uint8_t* desc, int cap, int* n);
+
+/* Batched many-frames mode (north_star): nframes independent 8UC1 frames already resident in HBM,
+ * frame f at d_gray + f*frame_stride, rows `stride` bytes apart.  Asynchronous on the context's
+ * stream; results stay in the handle's HBM buffers until the next call. */
+int pslfe_orb_extract_batch_device(pslfe_orb* orb, const uint8_t* d_gray, int nframes, int w, int h,
+                                   int stride, size_t frame_stride);
+/* Device views of the last batch's results: keypoints [nframes][cap] PslKeyPoint, descriptors
+ * [nframes][cap][32] u8, counts [nframes] int32; cap = *kp_cap. Valid until the next extract. */
+int pslfe_orb_results_device(pslfe_orb* orb, const PslKeyPoint** d_kps, const uint8_t** d_desc,
+                             const int32_t** d_counts, int* kp_cap);
+/* Copy frame `frame` of the last batch to the host (synchronises the stream). */
+int pslfe_orb_fetch(pslfe_orb* orb, int frame, PslKeyPoint* kps, uint8_t* desc, int cap, int* n);
+/* Host-buffer convenience: H2D + batch extract + D2H of everything.  kps [nframes][cap],
+ * desc [nframes][cap][32], counts [nframes]. */
+int pslfe_orb_extract_batch(pslfe_orb* orb, const uint8_t* gray, int nframes, int w, int h, int stride,
+                            size_t frame_stride, PslKeyPoint* kps, uint8_t* desc, int cap, int32_t* counts);
+
+/* Stage taps of the last batch, for parity tests against the oracle (host outputs, synchronous):
+ *  level image (blurred = 0: pyramid level == mvImagePyramid[level] ROI; 1: the 7x7 sigma-2 blur),
+ *  FAST candidates of a level in reference order (x, y relative to minBorder, score) == the
+ *  vToDistributeKeys of src/ORBextractor.cc:779-829, and keypoints after DistributeOctTree. */
+int pslfe_orb_debug_level_size(pslfe_orb* orb, int level, int* w, int* h);
+int pslfe_orb_debug_level_image(pslfe_orb* orb, int frame, int level, int blurred, uint8_t* out, int out_stride);
+int pslfe_orb_debug_candidates(pslfe_orb* orb, int frame, int level, int32_t* xys, int cap, int* n);
+int pslfe_orb_debug_level_keypoints(pslfe_orb* orb, int frame, int level, int32_t* xys, int cap, int* n);
+
+/* ---- descriptor matching --------------------------------------------------------------------- */
+/* == cv::BFMatcher(NORM_HAMMING).knnMatch(q, t, k=2) as used by LSDmatcher::matchNNR
+ *    add_src/LSDmatcher.cpp:354-376 and FrameBFMatch :492-516.  256-bit descriptors, row-major
+ *    32 B.  For query i: idx[2i], idx[2i+1] = best and second-best train rows (lower train index
+ *    first on equal distance), dist[...] the Hamming distances; -1 / 0x7fffffff where nt < k. */
+int pslfe_hamming_knn2(pslfe_ctx* ctx, const uint8_t* q, int nq, const uint8_t* t, int nt,
+                       int32_t* idx, int32_t* dist);
+/* Same on HBM-resident descriptors, asynchronous on the context's stream. */
+int pslfe_hamming_knn2_device(pslfe_ctx* ctx, const uint8_t* d_q, int nq, const uint8_t* d_t, int nt,
+                              int32_t* d_idx, int32_t* d_dist);
+
+/* One projected query of ORBmatcher::SearchByProjection (src/ORBmatcher.cc:1328-1470 and :45-129):
+ * what the host-side Tracking code knows about a map point before the window search. */
+typedef struct PslProjQuery {
+    float u, v;          /* projection into the current frame                                   */
+    float radius;        /* th * mvScaleFactors[octave] (:1381) or r * scale (:66)               */
+    float ur;            /* expected right coordinate u - mbf*invz (:1415) / mTrackProjXR (:92)  */
+    int32_t min_level;   /* GetFeaturesInArea level band (:1385-1390, :66)                       */
+    int32_t max_level;
+    float angle;         /* LastFrame.mvKeysUn[i].angle, for the rotation histogram (:1433)      */
+    int32_t blocks;      /* != 0: the map point has Observations()>0, so a keypoint it takes is
+                            skipped by later queries (:1401-1403)                                */
+} PslProjQuery;
+
+typedef struct pslfe_frame pslfe_frame;  /* keypoints of one frame bucketed on the 64x48 grid     */
+
+/* == Frame::AssignFeaturesToGrid src/Frame.cc:269-284 + PosInGrid :1040-1050 for the keypoints of
+ *    one frame (undistorted coordinates; PSL-SLAM's RGB-D YAMLs have zero distortion so these are
+ *    the extractor outputs).  min_x..max_y = mnMinX..mnMaxY image bounds (src/Frame.cc:1135).
+ *    uright: mvuRight per keypoint or NULL (= all -1). */
+int pslfe_frame_create(pslfe_ctx* ctx, int max_keypoints, pslfe_frame** out);
+void pslfe_frame_destroy(pslfe_frame* f);
+int pslfe_frame_set(pslfe_frame* f, const PslKeyPoint* kps, const uint8_t* desc, const float* uright,
+                    int n, float min_x, float min_y, float max_x, float max_y);
+/* Same from HBM-resident extractor results (frame `frame` of the last batch of `orb`). */
+int pslfe_frame_set_from_orb(pslfe_frame* f, pslfe_orb* orb, int frame, float min_x, float min_y,
+                             float max_x, float max_y);
+
+/* == ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono) src/ORBmatcher.cc:1328-1470
+ *    after the host has projected the last frame's map points (queries[i], qdesc[i] = map point i's
+ *    descriptor).  match[i] = index of the current-frame keypoint assigned to query i or -1, after
+ *    the TH_HIGH=100 gate and (check_orientation != 0) the 30-bin rotation-histogram filter;
+ *    *nmatches = the function's return value.  Sequential first-come semantics are preserved. */
+int pslfe_orb_search_by_projection_last(pslfe_frame* cur, const PslProjQuery* queries, const uint8_t* qdesc,
+                                        int nq, int check_orientation, int32_t* match, int* nmatches);
+/* == ORBmatcher::SearchByProjection(F, vpMapPoints, th) src/ORBmatcher.cc:45-129 (best / second
+ *    best with ratio test `nnratio` when both lie on the same octave). */
+int pslfe_orb_search_by_projection_map(pslfe_frame* cur, const PslProjQuery* queries, const uint8_t* qdesc,
+                                       int nq, float nnratio, int32_t* match, int* nmatches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,56 @@
+// ORACLE C interface (test infrastructure only; see header of orb_oracle.cpp).
+#ifndef PSL_ORACLE_H
+#define PSL_ORACLE_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+// == cv::KeyPoint (28 B): SURVEY.md Appendix B
+typedef struct PsoKeyPoint {
+    float x, y, size, angle, response;
+    int32_t octave, class_id;
+} PsoKeyPoint;
+
+// == line_descriptor::KeyLine (68 B), field order of
+// Thirdparty/line_descriptor/include/line_descriptor/descriptor_custom.hpp:107-146
+typedef struct PsoKeyLine {
+    float angle;
+    int32_t class_id, octave;
+    float pt_x, pt_y, response, size;
+    float startPointX, startPointY, endPointX, endPointY;
+    float sPointInOctaveX, sPointInOctaveY, ePointInOctaveX, ePointInOctaveY;
+    float lineLength;
+    int32_t numOfPixels;
+} PsoKeyLine;
+
+void* pso_orb_create(int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST);
+void pso_orb_destroy(void* h);
+int pso_orb_extract(void* h, const uint8_t* gray, int w, int hh, int stride, PsoKeyPoint* kps, uint8_t* desc, int cap);
+int pso_orb_quota(void* h, int level);
+float pso_orb_scale(void* h, int level);
+int pso_orb_umax(void* h, int v);
+int pso_orb_level_size(void* h, int level, int* w, int* hh);
+const uint8_t* pso_orb_level_ptr(void* h, int level);
+const uint8_t* pso_orb_blur_ptr(void* h, int level);
+int pso_orb_level_candidates(void* h, int level, int* xys, int cap);
+int pso_orb_level_keypoints(void* h, int level, PsoKeyPoint* out, int cap);
+
+int pso_distribute_octree(const int* xys, int n, int minX, int maxX, int minY, int maxY, int N, int* out_xys, int cap);
+void pso_resize_linear_u8(const uint8_t* src, int sw, int sh, uint8_t* dst, int dw, int dh);
+void pso_gaussian_blur_u8(const uint8_t* src, int w, int h, int ksize, double sigma, uint8_t* dst);
+void pso_gaussian_kernel_q8(int ksize, double sigma, int* K);
+int pso_fast_subimage(const uint8_t* img, int w, int h, int x0, int y0, int x1, int y1, int threshold, int* xys, int cap);
+float pso_fast_atan2_f(float y, float x);
+float pso_sinf_f(float x);
+float pso_cosf_f(float x);
+float pso_libm_sinf(float x);
+float pso_libm_cosf(float x);
+int pso_cvround_d(double v);
+const int8_t* pso_orb_pattern(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

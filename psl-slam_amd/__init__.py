@@ -1,0 +1,247 @@
+"""psl-slam_amd — MI355X-native feature front-end for PSL-SLAM (host-side Python mirror).
+
+Thin ctypes layer over the C ABI in include/pslfe.h (libpslfe.so, HIP/gfx950).  The class and
+method names follow the reference's C++ interfaces (include/ORBextractor.h:59,
+add_inc/LineExtractor.h:167, include/ORBmatcher.h, add_inc/LSDmatcher.h) so that the parity tests
+read like calls into the reference.  There is no CPU fallback: without the built library or
+without a gfx950 GPU every entry point raises.
+
+Import name: ``psl_slam_amd`` (root shim psl_slam_amd.py; the directory keeps the project's
+hyphenated name).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpslfe.so")
+
+KEYPOINT_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"),
+                           ("octave", "<i4"), ("class_id", "<i4")])
+KEYLINE_DTYPE = np.dtype([("angle", "<f4"), ("class_id", "<i4"), ("octave", "<i4"), ("pt_x", "<f4"), ("pt_y", "<f4"),
+                          ("response", "<f4"), ("size", "<f4"), ("startPointX", "<f4"), ("startPointY", "<f4"),
+                          ("endPointX", "<f4"), ("endPointY", "<f4"), ("sPointInOctaveX", "<f4"),
+                          ("sPointInOctaveY", "<f4"), ("ePointInOctaveX", "<f4"), ("ePointInOctaveY", "<f4"),
+                          ("lineLength", "<f4"), ("numOfPixels", "<i4")])
+PROJQUERY_DTYPE = np.dtype([("u", "<f4"), ("v", "<f4"), ("radius", "<f4"), ("ur", "<f4"), ("min_level", "<i4"),
+                            ("max_level", "<i4"), ("angle", "<f4"), ("blocks", "<i4")])
+assert KEYPOINT_DTYPE.itemsize == 28 and KEYLINE_DTYPE.itemsize == 68 and PROJQUERY_DTYPE.itemsize == 32
+
+
+class PslfeError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def build(force=False):
+    """Compile libpslfe.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("_pslfe_build", os.path.join(_HERE, "build.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.build(force=force)
+
+
+def lib():
+    """The loaded C-ABI library; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise PslfeError(f"{LIB_PATH} is missing: run `python psl-slam_amd/build.py` (needs hipcc); "
+                             "there is no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        L.pslfe_version.restype = C.c_char_p
+        L.pslfe_last_error.restype = C.c_char_p
+        L.pslfe_orb_scale_factor.restype = C.c_float
+        _lib = L
+    return _lib
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise PslfeError(f"{what} failed with code {rc}: {lib().pslfe_last_error().decode()}")
+
+
+def _ptr(a):
+    return None if a is None else C.c_void_p(a.ctypes.data)
+
+
+class Context:
+    """One per GPU (pslfe_ctx)."""
+
+    def __init__(self, device=0, stream=None):
+        self._h = C.c_void_p()
+        _check(lib().pslfe_ctx_create(C.c_int(device), C.byref(self._h)), "pslfe_ctx_create")
+        if stream is not None:
+            self.set_stream(stream)
+
+    def set_stream(self, hip_stream):
+        _check(lib().pslfe_ctx_set_stream(self._h, C.c_void_p(hip_stream)), "pslfe_ctx_set_stream")
+
+    def synchronize(self):
+        _check(lib().pslfe_ctx_synchronize(self._h), "pslfe_ctx_synchronize")
+
+    def profile(self, enable=True):
+        _check(lib().pslfe_ctx_profile(self._h, C.c_int(1 if enable else 0)), "pslfe_ctx_profile")
+
+    def profile_reset(self):
+        _check(lib().pslfe_ctx_profile_reset(self._h), "pslfe_ctx_profile_reset")
+
+    def stage_time(self, stage):
+        ms, n = C.c_double(), C.c_int()
+        _check(lib().pslfe_ctx_stage_time(self._h, stage.encode(), C.byref(ms), C.byref(n)), "pslfe_ctx_stage_time")
+        return ms.value, n.value
+
+    def close(self):
+        if self._h:
+            lib().pslfe_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_default_ctx = None
+
+
+def default_context():
+    global _default_ctx
+    if _default_ctx is None:
+        _default_ctx = Context(0)
+    return _default_ctx
+
+
+class ORBextractor:
+    """== ORB_SLAM2::ORBextractor (include/ORBextractor.h:45-114)."""
+
+    HARRIS_SCORE, FAST_SCORE = 0, 1
+
+    def __init__(self, nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, ctx=None, max_batch=1):
+        self.ctx = ctx or default_context()
+        self._h = C.c_void_p()
+        self.nlevels = nlevels
+        self.max_batch = max_batch
+        _check(lib().pslfe_orb_create(self.ctx._h, C.c_int(nfeatures), C.c_float(scaleFactor), C.c_int(nlevels),
+                                      C.c_int(iniThFAST), C.c_int(minThFAST), C.c_int(max_batch), C.byref(self._h)),
+               "pslfe_orb_create")
+
+    # getters of include/ORBextractor.h:63-84
+    def GetLevels(self):
+        return lib().pslfe_orb_levels(self._h)
+
+    def GetScaleFactor(self):
+        return lib().pslfe_orb_scale_factor(self._h)
+
+    def _factors(self):
+        a = [np.zeros(self.nlevels, np.float32) for _ in range(4)]
+        _check(lib().pslfe_orb_scale_factors(self._h, *[_ptr(x) for x in a]), "pslfe_orb_scale_factors")
+        return a
+
+    def GetScaleFactors(self):
+        return self._factors()[0]
+
+    def GetInverseScaleFactors(self):
+        return self._factors()[1]
+
+    def GetScaleSigmaSquares(self):
+        return self._factors()[2]
+
+    def GetInverseScaleSigmaSquares(self):
+        return self._factors()[3]
+
+    def features_per_level(self):
+        q = np.zeros(self.nlevels, np.int32)
+        _check(lib().pslfe_orb_features_per_level(self._h, _ptr(q)), "pslfe_orb_features_per_level")
+        return q
+
+    def max_keypoints(self, w, h):
+        n = lib().pslfe_orb_max_keypoints(self._h, C.c_int(w), C.c_int(h))
+        if n < 0:
+            _check(n, "pslfe_orb_max_keypoints")
+        return n
+
+    def __call__(self, image, mask=None):
+        """operator()(image, mask, keypoints, descriptors): mask is ignored as in the reference."""
+        if image is None or image.size == 0:
+            return np.zeros(0, KEYPOINT_DTYPE), np.zeros((0, 32), np.uint8)
+        assert image.dtype == np.uint8 and image.ndim == 2, "CV_8UC1 image expected"
+        h, w = image.shape
+        cap = self.max_keypoints(w, h)
+        kps = np.zeros(cap, KEYPOINT_DTYPE)
+        desc = np.zeros((cap, 32), np.uint8)
+        n = C.c_int()
+        _check(lib().pslfe_orb_extract(self._h, _ptr(image), C.c_int(w), C.c_int(h), C.c_int(image.strides[0]),
+                                       _ptr(kps), _ptr(desc), C.c_int(cap), C.byref(n)), "pslfe_orb_extract")
+        return kps[:n.value].copy(), desc[:n.value].copy()
+
+    def extract_batch(self, images):
+        """images: (F, h, w) uint8 host array -> list of (keypoints, descriptors)."""
+        assert images.dtype == np.uint8 and images.ndim == 3 and images.flags.c_contiguous
+        F, h, w = images.shape
+        cap = self.max_keypoints(w, h)
+        kps = np.zeros((F, cap), KEYPOINT_DTYPE)
+        desc = np.zeros((F, cap, 32), np.uint8)
+        counts = np.zeros(F, np.int32)
+        _check(lib().pslfe_orb_extract_batch(self._h, _ptr(images), C.c_int(F), C.c_int(w), C.c_int(h), C.c_int(w),
+                                             C.c_size_t(w * h), _ptr(kps), _ptr(desc), C.c_int(cap), _ptr(counts)),
+               "pslfe_orb_extract_batch")
+        return [(kps[f, :counts[f]].copy(), desc[f, :counts[f]].copy()) for f in range(F)]
+
+    def extract_batch_device(self, d_ptr, nframes, w, h, stride, frame_stride):
+        """Asynchronous extraction of frames resident in HBM (d_ptr = device address as int)."""
+        _check(lib().pslfe_orb_extract_batch_device(self._h, C.c_void_p(d_ptr), C.c_int(nframes), C.c_int(w), C.c_int(h),
+                                                    C.c_int(stride), C.c_size_t(frame_stride)),
+               "pslfe_orb_extract_batch_device")
+
+    def results_device(self):
+        k, d, c, cap = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_int()
+        _check(lib().pslfe_orb_results_device(self._h, C.byref(k), C.byref(d), C.byref(c), C.byref(cap)),
+               "pslfe_orb_results_device")
+        return k.value, d.value, c.value, cap.value
+
+    def fetch(self, frame, w, h):
+        cap = self.max_keypoints(w, h)
+        kps = np.zeros(cap, KEYPOINT_DTYPE)
+        desc = np.zeros((cap, 32), np.uint8)
+        n = C.c_int()
+        _check(lib().pslfe_orb_fetch(self._h, C.c_int(frame), _ptr(kps), _ptr(desc), C.c_int(cap), C.byref(n)), "pslfe_orb_fetch")
+        return kps[:n.value].copy(), desc[:n.value].copy()
+
+    # stage taps (parity tests)
+    def debug_level_image(self, frame, level, blurred=False):
+        w, h = C.c_int(), C.c_int()
+        _check(lib().pslfe_orb_debug_level_size(self._h, C.c_int(level), C.byref(w), C.byref(h)), "pslfe_orb_debug_level_size")
+        out = np.zeros((h.value, w.value), np.uint8)
+        _check(lib().pslfe_orb_debug_level_image(self._h, C.c_int(frame), C.c_int(level), C.c_int(1 if blurred else 0),
+                                                 _ptr(out), C.c_int(w.value)), "pslfe_orb_debug_level_image")
+        return out
+
+    def _debug_xys(self, fn, frame, level):
+        n = C.c_int()
+        _check(fn(self._h, C.c_int(frame), C.c_int(level), None, C.c_int(0), C.byref(n)), "pslfe_orb_debug")
+        out = np.zeros((max(n.value, 1), 3), np.int32)
+        _check(fn(self._h, C.c_int(frame), C.c_int(level), _ptr(out), C.c_int(out.shape[0]), C.byref(n)), "pslfe_orb_debug")
+        return out[:n.value]
+
+    def debug_candidates(self, frame, level):
+        return self._debug_xys(lib().pslfe_orb_debug_candidates, frame, level)
+
+    def debug_level_keypoints(self, frame, level):
+        return self._debug_xys(lib().pslfe_orb_debug_level_keypoints, frame, level)
+
+    def close(self):
+        if self._h:
+            lib().pslfe_orb_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

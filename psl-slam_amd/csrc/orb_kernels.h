@@ -1,0 +1,625 @@
+// HIP kernels of the ORB extraction path (gfx950, wave64). Product code.
+// Reference behaviour reproduced: src/ORBextractor.cc (ComputePyramid :1107-1132,
+// ComputeKeyPointsOctTree :765-853, DistributeOctTree :539-763, IC_Angle :77-104,
+// GaussianBlur :1085-1086, computeOrbDescriptor :108-147) with OpenCV-3.2 semantics for the
+// library calls.  All of it is integer / index work except the angle and
+// the rotated sampling coordinates, which use psl_device_math.h (no contraction).
+#ifndef PSL_ORB_KERNELS_H
+#define PSL_ORB_KERNELS_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/pslfe.h"
+#include "psl_device_math.h"
+
+#define PSL_EDGE 16          // minBorderX = EDGE_THRESHOLD - 3 (src/ORBextractor.cc:773)
+#define PSL_MAXCELL 64       // largest FAST cell interior handled by k_fast_cells
+#define PSL_FAST_TP 72       // LDS pitch of the (cell+6)^2 image tile
+#define PSL_FAST_SP 68       // LDS pitch of the (cell+2)^2 score map
+
+struct OrbLevelP {
+    int w, h, pitch;            // level image (levels >= 1 live in the pyramid block)
+    unsigned img_off;           // byte offset in the per-frame pyramid block (level 0: unused)
+    unsigned blur_off;          // byte offset in the per-frame blurred block
+    int nCols, nRows, wCell, hCell;
+    int maxBX, maxBY;           // maxBorderX / maxBorderY
+    int cell_off;               // first cell of this level in the per-frame cell arrays
+    int cand_off, cand_cap;     // dense candidate segment of this level (per frame)
+    int quota, kp_off, kp_cap;  // octree target N, output segment
+    int nIni;
+    float hX;
+    float scale, kpsize;
+    int tile_off, tiles_x, tiles_y;  // blur tiling (64 x 16 output tiles)
+};
+
+struct OrbParams {
+    int nlevels, ncells, cellcap, cand_total, kp_total, out_cap, iniTh, minTh, ntiles;
+    int blurK[7];
+    int umax[16];
+    OrbLevelP lv[PSLFE_MAX_LEVELS];
+};
+
+struct FrameSrc {          // where level 0 (the caller's image) and the derived levels live
+    const uint8_t* img0;   // frame 0 of the input batch
+    int stride0;
+    size_t fstride0;
+    uint8_t* pyr;          // per-frame pyramid block (levels >= 1)
+    size_t pyr_fstride;
+};
+
+__device__ __forceinline__ const uint8_t* psl_level_ptr(const OrbParams& P, const FrameSrc& S, int level, int frame, int* pitch) {
+    if (level == 0) { *pitch = S.stride0; return S.img0 + (size_t)frame * S.fstride0; }
+    *pitch = P.lv[level].pitch;
+    return S.pyr + (size_t)frame * S.pyr_fstride + P.lv[level].img_off;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Pyramid: level l from level l-1, cv::resize INTER_LINEAR 8UC1 fixed point (Appendix A.3).
+// Tables (xofs, alpha, yofs, beta) are built on the host exactly as OpenCV builds them.
+// One thread = 4 horizontally adjacent output pixels (one dword store).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pyr_resize(OrbParams P, FrameSrc S, int level,
+                                                     const int* __restrict__ xofs, const short2* __restrict__ alpha,
+                                                     const int* __restrict__ yofs, const short2* __restrict__ beta) {
+    const OrbLevelP L = P.lv[level];
+    const int frame = blockIdx.z;
+    const int dy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int x4 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
+    if (dy >= L.h || x4 >= L.pitch) return;
+    int spitch;
+    const uint8_t* src = psl_level_ptr(P, S, level - 1, frame, &spitch);
+    const int sw = P.lv[level - 1].w, sh = P.lv[level - 1].h;
+    uint8_t* dst = S.pyr + (size_t)frame * S.pyr_fstride + L.img_off + (size_t)dy * L.pitch;
+    int sy0 = yofs[dy], sy1 = sy0 + 1;
+    sy0 = sy0 < 0 ? 0 : (sy0 >= sh ? sh - 1 : sy0);
+    sy1 = sy1 < 0 ? 0 : (sy1 >= sh ? sh - 1 : sy1);
+    const short2 b = beta[dy];
+    const uint8_t* r0 = src + (size_t)sy0 * spitch;
+    const uint8_t* r1 = src + (size_t)sy1 * spitch;
+    uint32_t packed = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        int dx = x4 + j;
+        dx = dx < L.w ? dx : L.w - 1;  // padding columns repeat the last pixel
+        const int sx = xofs[dx];
+        const short2 a = alpha[dx];
+        int h0, h1;
+        if (sx + 1 < sw) {
+            h0 = r0[sx] * a.x + r0[sx + 1] * a.y;
+            h1 = r1[sx] * a.x + r1[sx + 1] * a.y;
+        } else {
+            h0 = r0[sx] * 2048;
+            h1 = r1[sx] * 2048;
+        }
+        const int v = ((((int)b.x * (h0 >> 4)) >> 16) + (((int)b.y * (h1 >> 4)) >> 16) + 2) >> 2;
+        packed |= (uint32_t)(v & 0xff) << (8 * j);
+    }
+    *reinterpret_cast<uint32_t*>(dst + x4) = packed;
+}
+
+// ---------------------------------------------------------------------------------------------
+// FAST-9/16 per cell with score NMS and the per-cell threshold fallback (src/ORBextractor.cc:789-829
+// around cv::FAST, Appendix A.6).  One workgroup = one cell of one level of one frame.
+//   S(p) = max over the 16 arcs of 9 ring pixels of min(v - ring), and of min(ring - v), minus 1
+//        = cornerScore<16>; p is a corner at threshold t  <=>  S(p) >= t.
+//   cv::FAST's NMS (score strictly greater than the 8 neighbours, scores outside the scanned
+//   interior = 0) at threshold t keeps exactly { p : S(p) >= t and S(p) > S(q) for all 8 q } because
+//   a neighbour below t has S(q) < t <= S(p) anyway.
+// Survivors are written in raster order: x | y << 12 | S << 24, (x, y) relative to minBorder.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int psl_fast_score(const uint8_t* c, const int tp) {
+    const int v = c[0];
+    int d[16];
+    d[0] = v - c[3 * tp];       d[1] = v - c[3 * tp + 1];   d[2] = v - c[2 * tp + 2];   d[3] = v - c[tp + 3];
+    d[4] = v - c[3];            d[5] = v - c[-tp + 3];      d[6] = v - c[-2 * tp + 2];  d[7] = v - c[-3 * tp + 1];
+    d[8] = v - c[-3 * tp];      d[9] = v - c[-3 * tp - 1];  d[10] = v - c[-2 * tp - 2]; d[11] = v - c[-tp - 3];
+    d[12] = v - c[-3];          d[13] = v - c[tp - 3];      d[14] = v - c[2 * tp - 2];  d[15] = v - c[3 * tp - 1];
+    int lo2[16], hi2[16], lo4[16], hi4[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { lo2[k] = min(d[k], d[(k + 1) & 15]); hi2[k] = max(d[k], d[(k + 1) & 15]); }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { lo4[k] = min(lo2[k], lo2[(k + 2) & 15]); hi4[k] = max(hi2[k], hi2[(k + 2) & 15]); }
+    int A = -256, B = 256;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int lo9 = min(min(lo4[k], lo4[(k + 4) & 15]), d[(k + 8) & 15]);
+        const int hi9 = max(max(hi4[k], hi4[(k + 4) & 15]), d[(k + 8) & 15]);
+        A = max(A, lo9);
+        B = min(B, hi9);
+    }
+    return max(A, -B) - 1;
+}
+
+__global__ __launch_bounds__(256) void k_fast_cells(OrbParams P, FrameSrc S, int* __restrict__ cellcnt,
+                                                     uint32_t* __restrict__ cellcand) {
+    __shared__ uint8_t s_tile[(PSL_MAXCELL + 6) * PSL_FAST_TP];
+    __shared__ uint8_t s_score[(PSL_MAXCELL + 2) * PSL_FAST_SP];
+    __shared__ int s_cnt[2][64];  // survivors per (pass, wave) at iniTh / minTh
+    __shared__ int s_off[2][65];
+
+    const int cell = blockIdx.x, frame = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int level = 0;
+    while (level + 1 < P.nlevels && cell >= P.lv[level + 1].cell_off) ++level;
+    const OrbLevelP L = P.lv[level];
+    const int ci = cell - L.cell_off;
+    const int i = ci / L.nCols, j = ci - i * L.nCols;
+    int* out_cnt = cellcnt + (size_t)frame * P.ncells + cell;
+    uint32_t* out = cellcand + ((size_t)frame * P.ncells + cell) * P.cellcap;
+
+    // cell window, src/ORBextractor.cc:789-806 (all quantities are integers held in floats there)
+    const int iniY = PSL_EDGE + i * L.hCell, iniX = PSL_EDGE + j * L.wCell;
+    int maxY = iniY + L.hCell + 6, maxX = iniX + L.wCell + 6;
+    if (maxY > L.maxBY) maxY = L.maxBY;
+    if (maxX > L.maxBX) maxX = L.maxBX;
+    const int tw = maxX - iniX, th = maxY - iniY;
+    if (iniY >= L.maxBY - 3 || iniX >= L.maxBX - 6 || tw < 7 || th < 7) {
+        if (tid == 0) *out_cnt = 0;
+        return;
+    }
+    const int iw = tw - 6, ih = th - 6;
+
+    int pitch;
+    const uint8_t* img = psl_level_ptr(P, S, level, frame, &pitch);
+    for (int y = wave; y < th; y += 4) {
+        const uint8_t* row = img + (size_t)(iniY + y) * pitch + iniX;
+        for (int x = lane; x < tw; x += 64) s_tile[y * PSL_FAST_TP + x] = row[x];
+    }
+    for (int k = tid; k < (ih + 2) * PSL_FAST_SP; k += 256) s_score[k] = 0;
+    if (tid < 128) (&s_cnt[0][0])[tid] = 0;
+    __syncthreads();
+
+    const int npix = iw * ih;
+    const int npass = (npix + 255) >> 8;
+    const int minTh = P.minTh, iniTh = P.iniTh;
+    for (int p = 0; p < npass; ++p) {
+        const int idx = p * 256 + tid;
+        if (idx < npix) {
+            const int y = idx / iw, x = idx - y * iw;
+            int s = psl_fast_score(&s_tile[(y + 3) * PSL_FAST_TP + x + 3], PSL_FAST_TP);
+            s = s < minTh ? 0 : (s > 255 ? 255 : s);
+            s_score[(y + 1) * PSL_FAST_SP + x + 1] = (uint8_t)s;
+        }
+    }
+    __syncthreads();
+
+    uint32_t keep_ini = 0, keep_min = 0;  // bit p: this thread's pixel of pass p survives
+    for (int p = 0; p < npass; ++p) {
+        const int idx = p * 256 + tid;
+        bool f_min = false, f_ini = false;
+        if (idx < npix) {
+            const int y = idx / iw, x = idx - y * iw;
+            const uint8_t* c = &s_score[(y + 1) * PSL_FAST_SP + x + 1];
+            const int s = c[0];
+            if (s > 0) {
+                const int m = max(max(max(c[-1], c[1]), max(c[-PSL_FAST_SP - 1], c[-PSL_FAST_SP])),
+                                  max(max(c[-PSL_FAST_SP + 1], c[PSL_FAST_SP - 1]), max(c[PSL_FAST_SP], c[PSL_FAST_SP + 1])));
+                f_min = s > m;
+                f_ini = f_min && s >= iniTh;
+            }
+        }
+        const unsigned long long b_min = __ballot(f_min), b_ini = __ballot(f_ini);
+        if (lane == 0) { s_cnt[0][p * 4 + wave] = __popcll(b_ini); s_cnt[1][p * 4 + wave] = __popcll(b_min); }
+        const unsigned long long below = (1ull << lane) - 1ull;
+        // remember the flag and the rank inside the wave (rank < 64 fits beside the flag later)
+        keep_ini |= (uint32_t)f_ini << p;
+        keep_min |= (uint32_t)f_min << p;
+        (void)below;
+    }
+    __syncthreads();
+    if (wave == 0) {  // exclusive scan of the 64 (pass, wave) counts, both thresholds
+        for (int t = 0; t < 2; ++t) {
+            const int v = s_cnt[t][lane];
+            int inc = v;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(inc, o); if (lane >= o) inc += u; }
+            s_off[t][lane] = inc - v;
+            if (lane == 63) s_off[t][64] = inc;
+        }
+    }
+    __syncthreads();
+    const int use = s_off[0][64] > 0 ? 0 : 1;  // retry at minTh only if iniTh found nothing (:812-816)
+    const int total = s_off[use][64];
+    const uint32_t keep = use == 0 ? keep_ini : keep_min;
+    for (int p = 0; p < npass; ++p) {
+        const bool f = (keep >> p) & 1;
+        const unsigned long long b = __ballot(f);
+        if (f) {
+            const int idx = p * 256 + tid;
+            const int y = idx / iw, x = idx - y * iw;
+            const int pos = s_off[use][p * 4 + wave] + __popcll(b & ((1ull << lane) - 1ull));
+            const uint32_t s = s_score[(y + 1) * PSL_FAST_SP + x + 1];
+            if (pos < P.cellcap)
+                out[pos] = (uint32_t)(x + 3 + j * L.wCell) | ((uint32_t)(y + 3 + i * L.hCell) << 12) | (s << 24);
+        }
+    }
+    if (tid == 0) *out_cnt = total < P.cellcap ? total : P.cellcap;
+}
+
+// ---------------------------------------------------------------------------------------------
+// DistributeOctTree as scans over arrays (prototype + fuzz against the list version:
+// tools/octree_proto.cpp).  One workgroup per (level, frame); one thread per list node, node id ==
+// list position; keys keep their original order and carry the id of the node that owns them.
+// ---------------------------------------------------------------------------------------------
+template <int BS>
+__device__ __forceinline__ int psl_block_excl_scan(int v, int* s_w, int* total) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(inc, o); if (lane >= o) inc += u; }
+    if (lane == 63) s_w[w] = inc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int acc = 0;
+        for (int k = 0; k < BS / 64; ++k) { const int t = s_w[k]; s_w[k] = acc; acc += t; }
+        s_w[BS / 64] = acc;
+    }
+    __syncthreads();
+    const int r = inc - v + s_w[w];
+    *total = s_w[BS / 64];
+    __syncthreads();
+    return r;
+}
+
+template <int BS>
+__global__ __launch_bounds__(BS) void k_octree(OrbParams P, const int* __restrict__ cellcnt,
+                                                const uint32_t* __restrict__ cellcand, int* __restrict__ celloff,
+                                                uint32_t* __restrict__ cand, uint16_t* __restrict__ knode,
+                                                uint32_t* __restrict__ lvlkp, int* __restrict__ lvlcnt) {
+    __shared__ short4 s_rect[2][BS];  // x0, y0, x1, y1
+    __shared__ int s_cntn[2][BS];
+    __shared__ int s_seq[2][BS];
+    __shared__ short2 s_mid[BS];
+    __shared__ int s_ccnt[BS][4];
+    __shared__ int s_c[BS];    // children per processing rank
+    __shared__ int s_cex[BS];  // exclusive scan of s_c over ranks
+    __shared__ short s_newpos[BS];
+    __shared__ short s_childpos[BS][4];
+    __shared__ unsigned long long s_best[BS];
+    __shared__ int s_w[BS / 64 + 1];
+    __shared__ int s_misc[4];  // 0: ndiv, 1: nToExpand, 2: carry
+
+    const int level = blockIdx.x, frame = blockIdx.y, tid = threadIdx.x;
+    const OrbLevelP L = P.lv[level];
+    const int ncell = L.nCols * L.nRows;
+    const int* ccnt_g = cellcnt + (size_t)frame * P.ncells + L.cell_off;
+    const uint32_t* ccand_g = cellcand + ((size_t)frame * P.ncells + L.cell_off) * P.cellcap;
+    int* coff_g = celloff + (size_t)frame * P.ncells + L.cell_off;
+    uint32_t* keys = cand + (size_t)frame * P.cand_total + L.cand_off;
+    uint16_t* kn = knode + (size_t)frame * P.cand_total + L.cand_off;
+
+    // ---- step 0: concatenate the cell lists in cell row-major order (== vToDistributeKeys order)
+    if (tid == 0) s_misc[2] = 0;
+    __syncthreads();
+    for (int base = 0; base < ncell; base += BS) {
+        const int c = base + tid;
+        const int v = c < ncell ? ccnt_g[c] : 0;
+        int tot;
+        const int ex = psl_block_excl_scan<BS>(v, s_w, &tot);
+        if (c < ncell) coff_g[c] = s_misc[2] + ex;
+        __syncthreads();
+        if (tid == 0) s_misc[2] += tot;
+        __syncthreads();
+    }
+    int K = s_misc[2];
+    if (K > L.cand_cap) K = L.cand_cap;  // cannot happen: cand_cap = sum of the cell capacities
+    for (int c = tid >> 6; c < ncell; c += BS / 64) {
+        const int n = ccnt_g[c], o = coff_g[c];
+        for (int t = tid & 63; t < n; t += 64)
+            if (o + t < K) keys[o + t] = ccand_g[(size_t)c * P.cellcap + t];
+    }
+    __syncthreads();
+
+    // ---- initial nodes (:541-583)
+    const int nIni = L.nIni;
+    const float hX = L.hX;
+    const int H = L.maxBY - PSL_EDGE;
+    if (tid < nIni) s_ccnt[tid][0] = 0;
+    __syncthreads();
+    for (int k = tid; k < K; k += BS) {
+        int idx = (int)PSL_FDIV((float)(keys[k] & 0xfff), hX);
+        if (idx >= nIni) idx = nIni - 1;
+        kn[k] = (uint16_t)idx;
+        atomicAdd(&s_ccnt[idx][0], 1);
+    }
+    __syncthreads();
+    int n;
+    {
+        const int cnt0 = tid < nIni ? s_ccnt[tid][0] : 0;
+        const int pos = psl_block_excl_scan<BS>(cnt0 > 0 ? 1 : 0, s_w, &n);
+        if (tid < nIni) {
+            s_newpos[tid] = (short)pos;
+            if (cnt0 > 0) {
+                s_rect[0][pos] = make_short4((short)(int)PSL_FMUL(hX, (float)tid), 0, (short)(int)PSL_FMUL(hX, (float)(tid + 1)), (short)H);
+                s_cntn[0][pos] = cnt0;
+                s_seq[0][pos] = tid;
+            }
+        }
+        __syncthreads();
+        for (int k = tid; k < K; k += BS) kn[k] = (uint16_t)s_newpos[kn[k]];
+        __syncthreads();
+    }
+    int seq = nIni, cur = 0;
+    bool phase2 = false;
+    const int N = L.quota;
+
+    while (true) {  // all loop-control values are workgroup-uniform
+        const int prevSize = n;
+        const int nxt = cur ^ 1;
+        int mycnt = 0;
+        short4 r4 = make_short4(0, 0, 0, 0);
+        int mx = 0, my = 0;
+        if (tid < n) {
+            mycnt = s_cntn[cur][tid];
+            r4 = s_rect[cur][tid];
+            mx = r4.x + ((r4.z - r4.x + 1) >> 1);  // UL.x + ceil((UR.x-UL.x)/2)  (:483)
+            my = r4.y + ((r4.w - r4.y + 1) >> 1);
+            s_mid[tid] = make_short2((short)mx, (short)my);
+            s_ccnt[tid][0] = 0; s_ccnt[tid][1] = 0; s_ccnt[tid][2] = 0; s_ccnt[tid][3] = 0;
+        }
+        if (tid == 0) { s_misc[0] = 0x7fffffff; s_misc[1] = 0; }
+        __syncthreads();
+        for (int k = tid; k < K; k += BS) {
+            const int nd = kn[k];
+            if (s_cntn[cur][nd] > 1) {
+                const uint32_t key = keys[k];
+                const short2 m = s_mid[nd];
+                const int q = ((int)(key & 0xfff) >= m.x ? 1 : 0) + ((int)((key >> 12) & 0xfff) >= m.y ? 2 : 0);
+                atomicAdd(&s_ccnt[nd][q], 1);
+            }
+        }
+        __syncthreads();
+        const bool isc = mycnt > 1;
+        int cc[4] = {0, 0, 0, 0}, c = 0, e = 0;
+        if (isc) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { cc[q] = s_ccnt[tid][q]; c += cc[q] > 0; e += cc[q] > 1; }
+        }
+        // processing rank among the nodes to divide
+        int rank, ncand;
+        if (!phase2) {
+            rank = psl_block_excl_scan<BS>(isc ? 1 : 0, s_w, &ncand);  // list order (:597-660)
+        } else {
+            // sort by (size, creation sequence) descending (:684-685, convention H1)
+            const int myseq = tid < n ? s_seq[cur][tid] : 0;
+            int r = 0;
+            if (isc)
+                for (int jn = 0; jn < n; ++jn) {
+                    const int cj = s_cntn[cur][jn], sj = s_seq[cur][jn];
+                    r += (cj > 1) && (cj > mycnt || (cj == mycnt && sj > myseq));
+                }
+            rank = r;
+            int dummy = psl_block_excl_scan<BS>(isc ? 1 : 0, s_w, &ncand);
+            (void)dummy;
+        }
+        if (isc) s_c[rank] = c;
+        __syncthreads();
+        int C_all;
+        {
+            const int v = tid < ncand ? s_c[tid] : 0;
+            const int ex = psl_block_excl_scan<BS>(v, s_w, &C_all);
+            if (tid < ncand) {
+                s_cex[tid] = ex;
+                // list size after processing rank tid: n + (children so far) - (nodes erased so far)
+                if (phase2 && n + (ex + v) - (tid + 1) >= N) atomicMin(&s_misc[0], tid + 1);  // break (:737-738)
+            }
+        }
+        __syncthreads();
+        const int ndiv = (phase2 && s_misc[0] < ncand) ? s_misc[0] : ncand;
+        const int C = ndiv == ncand ? C_all : s_cex[ndiv];
+        const bool divided = isc && rank < ndiv;
+        int dummyTotal;
+        const int keep = psl_block_excl_scan<BS>((tid < n && !divided) ? 1 : 0, s_w, &dummyTotal);
+        if (tid < n) {
+            if (!divided) {
+                const int pos = C + keep;
+                s_newpos[tid] = (short)pos;
+                s_rect[nxt][pos] = r4;
+                s_cntn[nxt][pos] = mycnt;
+                s_seq[nxt][pos] = s_seq[cur][tid];
+            } else {
+                s_newpos[tid] = -1;
+                const int cex = s_cex[rank];
+                const int front = C - (cex + c);  // children of later-processed nodes sit in front (push_front)
+                int seen = 0;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (cc[q] == 0) continue;
+                    const int pos = front + (c - 1 - seen);
+                    s_rect[nxt][pos] = make_short4((q & 1) ? (short)mx : r4.x, (q & 2) ? (short)my : r4.y,
+                                                   (q & 1) ? r4.z : (short)mx, (q & 2) ? r4.w : (short)my);
+                    s_cntn[nxt][pos] = cc[q];
+                    s_seq[nxt][pos] = seq + cex + seen;
+                    s_childpos[tid][q] = (short)pos;
+                    ++seen;
+                }
+                if (e) atomicAdd(&s_misc[1], e);
+            }
+        }
+        __syncthreads();
+        for (int k = tid; k < K; k += BS) {
+            const int nd = kn[k];
+            const int np = s_newpos[nd];
+            if (np >= 0) kn[k] = (uint16_t)np;
+            else {
+                const uint32_t key = keys[k];
+                const short2 m = s_mid[nd];
+                const int q = ((int)(key & 0xfff) >= m.x ? 1 : 0) + ((int)((key >> 12) & 0xfff) >= m.y ? 2 : 0);
+                kn[k] = (uint16_t)s_childpos[nd][q];
+            }
+        }
+        const int nToExpand = s_misc[1];
+        __syncthreads();
+        n = C + n - ndiv;
+        seq += C;
+        cur = nxt;
+        if (n >= N || n == prevSize) break;                       // (:665-669, :741-742)
+        if (!phase2 && n + nToExpand * 3 > N) phase2 = true;      // (:670)
+    }
+
+    // ---- best key of each node: max response, first in key order (:746-760)
+    if (tid < n) s_best[tid] = 0ull;
+    __syncthreads();
+    for (int k = tid; k < K; k += BS) {
+        const unsigned long long v = ((unsigned long long)(keys[k] >> 24) << 32) | (unsigned long long)(0xffffffffu - (uint32_t)k);
+        atomicMax(&s_best[kn[k]], v);
+    }
+    __syncthreads();
+    uint32_t* outk = lvlkp + (size_t)frame * P.kp_total + L.kp_off;
+    if (tid < n && tid < L.kp_cap) {
+        const uint32_t k = 0xffffffffu - (uint32_t)(s_best[tid] & 0xffffffffull);
+        outk[tid] = keys[k];
+    }
+    if (tid == 0) lvlcnt[(size_t)frame * P.nlevels + level] = n < L.kp_cap ? n : L.kp_cap;
+}
+
+// ---------------------------------------------------------------------------------------------
+// GaussianBlur 7x7 sigma 2, BORDER_REFLECT_101, on every (un-padded) level: OpenCV 3.2 8-bit
+// path = integer kernel round(k*256), 32-bit row sums, (v + 2^15) >> 16 (Appendix A.4).
+// 64 x 16 output tile per workgroup, separable through LDS (row sums fit 16 bits: 255*257).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int psl_reflect101(int p, int n) {
+    if (n == 1) return 0;
+    while (p < 0 || p >= n) p = p < 0 ? -p : 2 * n - 2 - p;
+    return p;
+}
+
+__global__ __launch_bounds__(256) void k_blur7(OrbParams P, FrameSrc S, uint8_t* __restrict__ blur, size_t blur_fstride) {
+    __shared__ uint8_t s_in[22][72];
+    __shared__ uint16_t s_row[22][64];
+    const int tile = blockIdx.x, frame = blockIdx.y, tid = threadIdx.x;
+    int level = 0;
+    while (level + 1 < P.nlevels && tile >= P.lv[level + 1].tile_off) ++level;
+    const OrbLevelP L = P.lv[level];
+    const int t = tile - L.tile_off;
+    const int ty = t / L.tiles_x, tx = t - ty * L.tiles_x;
+    const int x0 = tx * 64, y0 = ty * 16;
+    int pitch;
+    const uint8_t* img = psl_level_ptr(P, S, level, frame, &pitch);
+    for (int k = tid; k < 22 * 70; k += 256) {
+        const int yy = k / 70, xx = k - yy * 70;
+        const int gy = psl_reflect101(y0 + yy - 3, L.h), gx = psl_reflect101(x0 + xx - 3, L.w);
+        s_in[yy][xx] = img[(size_t)gy * pitch + gx];
+    }
+    __syncthreads();
+    for (int k = tid; k < 22 * 64; k += 256) {
+        const int yy = k >> 6, xx = k & 63;
+        int s = 0;
+#pragma unroll
+        for (int j = 0; j < 7; ++j) s += P.blurK[j] * s_in[yy][xx + j];
+        s_row[yy][xx] = (uint16_t)s;
+    }
+    __syncthreads();
+    const int oy = tid >> 4, ox = (tid & 15) * 4;
+    if (y0 + oy >= L.h || x0 + ox >= L.pitch) return;
+    uint32_t packed = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        int s = 0;
+#pragma unroll
+        for (int k = 0; k < 7; ++k) s += P.blurK[k] * (int)s_row[oy + k][ox + j];
+        int v = (s + (1 << 15)) >> 16;
+        v = v > 255 ? 255 : v;
+        packed |= (uint32_t)v << (8 * j);
+    }
+    uint8_t* dst = blur + (size_t)frame * blur_fstride + L.blur_off + (size_t)(y0 + oy) * L.pitch + x0 + ox;
+    *reinterpret_cast<uint32_t*>(dst) = packed;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Orientation (IC_Angle) + rBRIEF + final KeyPoint record: one wave per keypoint.
+// Output order: levels 0..n-1 concatenated, inside a level the octree's list order (:1076-1103).
+// ---------------------------------------------------------------------------------------------
+__constant__ int8_t c_orb_pattern[1024] = {
+#include "orb_pattern.inc"
+};
+
+__global__ __launch_bounds__(256) void k_orient_describe(OrbParams P, FrameSrc S, const uint8_t* __restrict__ blur,
+                                                          size_t blur_fstride, const uint32_t* __restrict__ lvlkp,
+                                                          const int* __restrict__ lvlcnt, PslKeyPoint* __restrict__ kps,
+                                                          uint8_t* __restrict__ desc, int* __restrict__ counts) {
+    const int frame = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int slot = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int* lc = lvlcnt + (size_t)frame * P.nlevels;
+    int level = -1, idx = slot, total = 0;
+    for (int l = 0; l < P.nlevels; ++l) {
+        const int c = lc[l];
+        if (level < 0 && idx < c) level = l;
+        if (level < 0) idx -= c;
+        total += c;
+    }
+    if (slot == 0 && lane == 0) counts[frame] = total < P.out_cap ? total : P.out_cap;
+    if (level < 0 || slot >= P.out_cap) return;
+    const OrbLevelP L = P.lv[level];
+    const uint32_t key = lvlkp[(size_t)frame * P.kp_total + L.kp_off + idx];
+    const int cx = (int)(key & 0xfff) + PSL_EDGE, cy = (int)((key >> 12) & 0xfff) + PSL_EDGE;
+    int pitch;
+    const uint8_t* img = psl_level_ptr(P, S, level, frame, &pitch);
+
+    // intensity centroid over the radius-15 disc: lanes 0..30 take column u = lane-15 for v >= 0,
+    // lanes 32..62 the same column for v < 0
+    int m10 = 0, m01 = 0;
+    {
+        const int col = lane & 31;
+        if (col < 31) {
+            const int u = col - 15, au = u < 0 ? -u : u;
+            const uint8_t* c = img + (size_t)cy * pitch + cx + u;
+            int colsum = 0, vsum = 0;
+            if (lane < 32) {
+                for (int v = 0; v <= 15; ++v)
+                    if (au <= P.umax[v]) { const int val = c[(ptrdiff_t)v * pitch]; colsum += val; vsum += v * val; }
+            } else {
+                for (int v = 1; v <= 15; ++v)
+                    if (au <= P.umax[v]) { const int val = c[-(ptrdiff_t)v * pitch]; colsum += val; vsum -= v * val; }
+            }
+            m10 = u * colsum;
+            m01 = vsum;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { m10 += __shfl_xor(m10, o); m01 += __shfl_xor(m01, o); }
+    }
+    const float angle = psl_fast_atan2((float)m01, (float)m10);
+
+    // rBRIEF: lane i evaluates comparisons 4i..4i+3
+    const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
+    float a, b;
+    psl_sincosf(PSL_FMUL(angle, factorPI), &b, &a);  // a = cos, b = sin
+    const uint8_t* bl = blur + (size_t)frame * blur_fstride + L.blur_off + (size_t)cy * L.pitch + cx;
+    uint32_t nib = 0;
+#pragma unroll
+    for (int cmp = 0; cmp < 4; ++cmp) {
+        const int8_t* pt = &c_orb_pattern[(lane * 4 + cmp) * 4];
+        const float x0 = (float)pt[0], y0 = (float)pt[1], x1 = (float)pt[2], y1 = (float)pt[3];
+        const int r0 = psl_cvround_f(PSL_FADD(PSL_FMUL(x0, b), PSL_FMUL(y0, a)));
+        const int c0 = psl_cvround_f(PSL_FSUB(PSL_FMUL(x0, a), PSL_FMUL(y0, b)));
+        const int r1 = psl_cvround_f(PSL_FADD(PSL_FMUL(x1, b), PSL_FMUL(y1, a)));
+        const int c1 = psl_cvround_f(PSL_FSUB(PSL_FMUL(x1, a), PSL_FMUL(y1, b)));
+        const int t0 = bl[(ptrdiff_t)r0 * L.pitch + c0], t1 = bl[(ptrdiff_t)r1 * L.pitch + c1];
+        nib |= (uint32_t)(t0 < t1) << cmp;
+    }
+    uint32_t v = nib << ((lane & 1) * 4);           // byte lane/2
+    v |= __shfl_xor(v, 1);
+    v <<= ((lane >> 1) & 3) * 8;                    // dword lane/8
+    v |= __shfl_xor(v, 2);
+    v |= __shfl_xor(v, 4);
+    const size_t o = (size_t)frame * P.out_cap + slot;
+    if ((lane & 7) == 0) reinterpret_cast<uint32_t*>(desc + o * 32)[lane >> 3] = v;
+    if (lane < 7) {
+        float f;
+        const float px = (float)cx, py = (float)cy;
+        switch (lane) {
+            case 0: f = level ? PSL_FMUL(px, L.scale) : px; break;
+            case 1: f = level ? PSL_FMUL(py, L.scale) : py; break;
+            case 2: f = L.kpsize; break;
+            case 3: f = angle; break;
+            case 4: f = (float)(key >> 24); break;
+            case 5: f = __int_as_float(level); break;
+            default: f = __int_as_float(-1); break;
+        }
+        reinterpret_cast<float*>(kps + o)[lane] = f;
+    }
+}
+
+#endif

@@ -1,0 +1,137 @@
+// libpslfe: context, error reporting, stage timing. Product code.
+#include <stdarg.h>
+#include <string.h>
+
+#include "pslfe_internal.h"
+
+static thread_local char g_err[512] = "";
+
+void pslfe_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int pslfe_ctx::stage_begin(const char* name, hipEvent_t* a, hipEvent_t* b) {
+    (void)name;
+    PSL_HIP(hipEventCreate(a));
+    PSL_HIP(hipEventCreate(b));
+    PSL_HIP(hipEventRecord(*a, stream));
+    return PSLFE_OK;
+}
+
+int pslfe_ctx::stage_end(const char* name, hipEvent_t a, hipEvent_t b) {
+    PSL_HIP(hipEventRecord(b, stream));
+    pending.push_back({a, b, name});
+    return PSLFE_OK;
+}
+
+int pslfe_ctx::resolve_pending() {
+    for (auto& p : pending) {
+        PSL_HIP(hipEventSynchronize(p.b));
+        float ms = 0;
+        PSL_HIP(hipEventElapsedTime(&ms, p.a, p.b));
+        StageTimer& t = stages[p.stage];
+        t.ms += ms;
+        t.launches += 1;
+        hipEventDestroy(p.a);
+        hipEventDestroy(p.b);
+    }
+    pending.clear();
+    return PSLFE_OK;
+}
+
+extern "C" {
+
+const char* pslfe_version(void) { return "pslfe 0.1 (gfx950)"; }
+const char* pslfe_last_error(void) { return g_err; }
+
+int pslfe_ctx_create(int device, pslfe_ctx** out) {
+    PSL_REQUIRE(out, PSLFE_E_INVALID, "pslfe_ctx_create: out is NULL");
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) {
+        pslfe_set_error("pslfe_ctx_create: no HIP device (%s); this library has no CPU fallback",
+                        e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+        return PSLFE_E_NODEVICE;
+    }
+    PSL_REQUIRE(device >= 0 && device < ndev, PSLFE_E_INVALID, "pslfe_ctx_create: device %d of %d", device, ndev);
+    if (hipSetDevice(device) != hipSuccess) {
+        pslfe_set_error("pslfe_ctx_create: hipSetDevice(%d) failed", device);
+        return PSLFE_E_NODEVICE;
+    }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) {
+        pslfe_set_error("pslfe_ctx_create: hipGetDeviceProperties failed");
+        return PSLFE_E_NODEVICE;
+    }
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        pslfe_set_error("pslfe_ctx_create: device %d is %s; this library is built for gfx950 only", device, prop.gcnArchName);
+        return PSLFE_E_NODEVICE;
+    }
+    pslfe_ctx* c = new pslfe_ctx();
+    c->device = device;
+    c->cu_count = prop.multiProcessorCount;
+    if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) {
+        delete c;
+        pslfe_set_error("pslfe_ctx_create: hipStreamCreate failed");
+        return PSLFE_E_HIP;
+    }
+    c->stream = c->own_stream;
+    *out = c;
+    return PSLFE_OK;
+}
+
+void pslfe_ctx_destroy(pslfe_ctx* ctx) {
+    if (!ctx) return;
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+    ctx->resolve_pending();
+    if (ctx->own_stream) hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+}
+
+int pslfe_ctx_set_stream(pslfe_ctx* ctx, void* hip_stream) {
+    PSL_REQUIRE(ctx, PSLFE_E_INVALID, "pslfe_ctx_set_stream: ctx is NULL");
+    PSL_HIP(hipSetDevice(ctx->device));
+    PSL_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return PSLFE_OK;
+}
+
+int pslfe_ctx_synchronize(pslfe_ctx* ctx) {
+    PSL_REQUIRE(ctx, PSLFE_E_INVALID, "pslfe_ctx_synchronize: ctx is NULL");
+    PSL_HIP(hipSetDevice(ctx->device));
+    PSL_HIP(hipStreamSynchronize(ctx->stream));
+    return ctx->resolve_pending();
+}
+
+int pslfe_ctx_profile(pslfe_ctx* ctx, int enable) {
+    PSL_REQUIRE(ctx, PSLFE_E_INVALID, "pslfe_ctx_profile: ctx is NULL");
+    int rc = pslfe_ctx_synchronize(ctx);
+    if (rc) return rc;
+    ctx->profile = enable != 0;
+    return PSLFE_OK;
+}
+
+int pslfe_ctx_profile_reset(pslfe_ctx* ctx) {
+    PSL_REQUIRE(ctx, PSLFE_E_INVALID, "pslfe_ctx_profile_reset: ctx is NULL");
+    int rc = pslfe_ctx_synchronize(ctx);
+    if (rc) return rc;
+    ctx->stages.clear();
+    return PSLFE_OK;
+}
+
+int pslfe_ctx_stage_time(pslfe_ctx* ctx, const char* stage, double* ms_total, int* launches) {
+    PSL_REQUIRE(ctx && stage, PSLFE_E_INVALID, "pslfe_ctx_stage_time: NULL argument");
+    int rc = pslfe_ctx_synchronize(ctx);
+    if (rc) return rc;
+    auto it = ctx->stages.find(stage);
+    if (ms_total) *ms_total = it == ctx->stages.end() ? 0.0 : it->second.ms;
+    if (launches) *launches = it == ctx->stages.end() ? 0 : it->second.launches;
+    return PSLFE_OK;
+}
+
+}  // extern "C"

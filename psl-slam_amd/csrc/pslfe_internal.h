@@ -1,0 +1,70 @@
+// Internal declarations of libpslfe (host side). Product code.
+#ifndef PSLFE_INTERNAL_H
+#define PSLFE_INTERNAL_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/pslfe.h"
+
+void pslfe_set_error(const char* fmt, ...);
+
+#define PSL_HIP(call)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (call);                                                                    \
+        if (e_ != hipSuccess) {                                                                    \
+            pslfe_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e_));  \
+            return PSLFE_E_HIP;                                                                    \
+        }                                                                                          \
+    } while (0)
+
+#define PSL_REQUIRE(cond, code, ...)      \
+    do {                                  \
+        if (!(cond)) {                    \
+            pslfe_set_error(__VA_ARGS__); \
+            return (code);                \
+        }                                 \
+    } while (0)
+
+struct StageTimer {
+    double ms = 0;
+    int launches = 0;
+};
+
+struct pslfe_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;  // stream in use (own or external)
+    bool profile = false;
+    std::map<std::string, StageTimer> stages;
+    // event pool for profile mode: (start, stop, stage) triples resolved at synchronize
+    struct Pending { hipEvent_t a, b; std::string stage; };
+    std::vector<Pending> pending;
+    int cu_count = 0;
+
+    int stage_begin(const char* name, hipEvent_t* a, hipEvent_t* b);
+    int stage_end(const char* name, hipEvent_t a, hipEvent_t b);
+    int resolve_pending();
+};
+
+// RAII-less helper used as: PSL_STAGE_BEGIN(ctx,"orb.fast"); launch...; PSL_STAGE_END(ctx,"orb.fast");
+#define PSL_STAGE_BEGIN(ctx, name)                                  \
+    hipEvent_t ev_a_ = nullptr, ev_b_ = nullptr;                    \
+    if ((ctx)->profile) {                                           \
+        int rc_ = (ctx)->stage_begin(name, &ev_a_, &ev_b_);         \
+        if (rc_) return rc_;                                        \
+    }
+#define PSL_STAGE_END(ctx, name)                                    \
+    if ((ctx)->profile) {                                           \
+        int rc_ = (ctx)->stage_end(name, ev_a_, ev_b_);             \
+        if (rc_) return rc_;                                        \
+    }
+
+static inline size_t psl_align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+#endif

@@ -1,0 +1,109 @@
+"""ctypes access to the ORACLE (oracle/libpsl_oracle.so): test infrastructure only."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ODIR = os.path.join(ROOT, "oracle")
+SO = os.path.join(ODIR, "libpsl_oracle.so")
+
+KEYPOINT_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"),
+                           ("octave", "<i4"), ("class_id", "<i4")])
+
+
+def build():
+    srcs = [os.path.join(ODIR, f) for f in os.listdir(ODIR) if f.endswith((".cpp", ".h", ".inc", "Makefile"))]
+    if not os.path.exists(SO) or any(os.path.getmtime(s) > os.path.getmtime(SO) for s in srcs):
+        subprocess.run(["make", "-C", ODIR], check=True, capture_output=True)
+    return SO
+
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(SO)
+        L.pso_orb_create.restype = C.c_void_p
+        L.pso_orb_create.argtypes = [C.c_int, C.c_float, C.c_int, C.c_int, C.c_int]
+        L.pso_orb_destroy.argtypes = [C.c_void_p]
+        L.pso_orb_extract.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+        L.pso_orb_quota.argtypes = [C.c_void_p, C.c_int]
+        L.pso_orb_scale.argtypes = [C.c_void_p, C.c_int]
+        L.pso_orb_scale.restype = C.c_float
+        L.pso_orb_umax.argtypes = [C.c_void_p, C.c_int]
+        L.pso_orb_level_size.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.pso_orb_level_ptr.argtypes = [C.c_void_p, C.c_int]
+        L.pso_orb_level_ptr.restype = C.c_void_p
+        L.pso_orb_blur_ptr.argtypes = [C.c_void_p, C.c_int]
+        L.pso_orb_blur_ptr.restype = C.c_void_p
+        L.pso_orb_level_candidates.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+        L.pso_orb_level_keypoints.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+        L.pso_distribute_octree.argtypes = [C.c_void_p, C.c_int] + [C.c_int] * 5 + [C.c_void_p, C.c_int]
+        L.pso_resize_linear_u8.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int]
+        L.pso_gaussian_blur_u8.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_void_p]
+        L.pso_gaussian_kernel_q8.argtypes = [C.c_int, C.c_double, C.c_void_p]
+        L.pso_fast_subimage.argtypes = [C.c_void_p] + [C.c_int] * 7 + [C.c_void_p, C.c_int]
+        for f in ("pso_fast_atan2_f",):
+            getattr(L, f).argtypes = [C.c_float, C.c_float]
+            getattr(L, f).restype = C.c_float
+        for f in ("pso_sinf_f", "pso_cosf_f", "pso_libm_sinf", "pso_libm_cosf"):
+            getattr(L, f).argtypes = [C.c_float]
+            getattr(L, f).restype = C.c_float
+        L.pso_cvround_d.argtypes = [C.c_double]
+        L.pso_orb_pattern.restype = C.POINTER(C.c_int8)
+        _lib = L
+    return _lib
+
+
+class OracleORB:
+    """CPU restatement of ORBextractor (oracle/orb_oracle.cpp) with stage taps."""
+
+    def __init__(self, nfeatures=1000, scaleFactor=1.2, nlevels=8, iniThFAST=20, minThFAST=7):
+        self.L = load()
+        self.nlevels = nlevels
+        self.h = self.L.pso_orb_create(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST)
+        assert self.h
+
+    def __call__(self, image):
+        image = np.ascontiguousarray(image)
+        hh, ww = image.shape
+        cap = 8 * 4096
+        kps = np.zeros(cap, KEYPOINT_DTYPE)
+        desc = np.zeros((cap, 32), np.uint8)
+        n = self.L.pso_orb_extract(self.h, image.ctypes.data, ww, hh, image.strides[0], kps.ctypes.data, desc.ctypes.data, cap)
+        assert n >= 0
+        return kps[:n].copy(), desc[:n].copy()
+
+    def quota(self):
+        return [self.L.pso_orb_quota(self.h, l) for l in range(self.nlevels)]
+
+    def level_image(self, level, blurred=False):
+        w, h = C.c_int(), C.c_int()
+        assert self.L.pso_orb_level_size(self.h, level, C.byref(w), C.byref(h)) == 0
+        p = self.L.pso_orb_blur_ptr(self.h, level) if blurred else self.L.pso_orb_level_ptr(self.h, level)
+        if not p:
+            return None
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), (h.value, w.value)).copy()
+
+    def candidates(self, level):
+        n = self.L.pso_orb_level_candidates(self.h, level, None, 0)
+        out = np.zeros((max(n, 1), 3), np.int32)
+        self.L.pso_orb_level_candidates(self.h, level, out.ctypes.data, n)
+        return out[:n]
+
+    def level_keypoints(self, level):
+        n = self.L.pso_orb_level_keypoints(self.h, level, None, 0)
+        out = np.zeros(max(n, 1), KEYPOINT_DTYPE)
+        self.L.pso_orb_level_keypoints(self.h, level, out.ctypes.data, n)
+        return out[:n]
+
+    def __del__(self):
+        try:
+            self.L.pso_orb_destroy(self.h)
+        except Exception:
+            pass
