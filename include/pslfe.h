@@ -157,31 +157,52 @@ typedef struct PslProjQuery {
                             skipped by later queries (:1401-1403)                                */
 } PslProjQuery;
 
-typedef struct pslfe_frame pslfe_frame;  /* keypoints of one frame bucketed on the 64x48 grid     */
+typedef struct pslfe_frame pslfe_frame;  /* keypoints of up to max_frames frames, each bucketed on
+                                             the 64x48 grid of include/Frame.h:45-46            */
 
 /* == Frame::AssignFeaturesToGrid src/Frame.cc:269-284 + PosInGrid :1040-1050 for the keypoints of
- *    one frame (undistorted coordinates; PSL-SLAM's RGB-D YAMLs have zero distortion so these are
- *    the extractor outputs).  min_x..max_y = mnMinX..mnMaxY image bounds (src/Frame.cc:1135).
- *    uright: mvuRight per keypoint or NULL (= all -1). */
-int pslfe_frame_create(pslfe_ctx* ctx, int max_keypoints, pslfe_frame** out);
+ *    one frame, stored in `slot` (0 <= slot < max_frames).  Coordinates are the undistorted ones
+ *    (mvKeysUn; PSL-SLAM's RGB-D YAMLs have zero distortion, so these are the extractor outputs).
+ *    min_x..max_y = mnMinX..mnMaxY (src/Frame.cc:1135-1168).  uright: mvuRight or NULL (= all -1). */
+int pslfe_frame_create(pslfe_ctx* ctx, int max_keypoints, int max_frames, pslfe_frame** out);
 void pslfe_frame_destroy(pslfe_frame* f);
-int pslfe_frame_set(pslfe_frame* f, const PslKeyPoint* kps, const uint8_t* desc, const float* uright,
+int pslfe_frame_set(pslfe_frame* f, int slot, const PslKeyPoint* kps, const uint8_t* desc, const float* uright,
                     int n, float min_x, float min_y, float max_x, float max_y);
-/* Same from HBM-resident extractor results (frame `frame` of the last batch of `orb`). */
-int pslfe_frame_set_from_orb(pslfe_frame* f, pslfe_orb* orb, int frame, float min_x, float min_y,
-                             float max_x, float max_y);
+/* All frames of the last batch of `orb` -> slots 0..nframes-1, HBM to HBM, asynchronous. */
+int pslfe_frame_set_from_orb(pslfe_frame* f, pslfe_orb* orb, float min_x, float min_y, float max_x, float max_y);
+/* Tap for parity tests: CSR of mGrid in the order GetFeaturesInArea visits it (cell = ix*48+iy):
+ * start[64*48+1], idx[n]. */
+int pslfe_frame_debug_grid(pslfe_frame* f, int slot, int32_t* start, int32_t* idx, int cap, int* n);
 
 /* == ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono) src/ORBmatcher.cc:1328-1470
- *    after the host has projected the last frame's map points (queries[i], qdesc[i] = map point i's
- *    descriptor).  match[i] = index of the current-frame keypoint assigned to query i or -1, after
- *    the TH_HIGH=100 gate and (check_orientation != 0) the 30-bin rotation-histogram filter;
- *    *nmatches = the function's return value.  Sequential first-come semantics are preserved. */
-int pslfe_orb_search_by_projection_last(pslfe_frame* cur, const PslProjQuery* queries, const uint8_t* qdesc,
-                                        int nq, int check_orientation, int32_t* match, int* nmatches);
-/* == ORBmatcher::SearchByProjection(F, vpMapPoints, th) src/ORBmatcher.cc:45-129 (best / second
- *    best with ratio test `nnratio` when both lie on the same octave). */
-int pslfe_orb_search_by_projection_map(pslfe_frame* cur, const PslProjQuery* queries, const uint8_t* qdesc,
-                                       int nq, float nnratio, int32_t* match, int* nmatches);
+ *    after the host has projected the last frame's map points: queries[i] / qdesc[i] (32 B) describe
+ *    map point i.  taken[c] != 0 (or NULL = none): current keypoint c already holds a map point with
+ *    Observations()>0 and is skipped (:1401-1403).  Outputs: match[i] = current keypoint given to
+ *    query i or -1 (TH_HIGH = 100 gate, then - if check_orientation - the rotation-histogram filter
+ *    :1448-1467); assigned[c] (may be NULL) = query whose map point ends up in
+ *    CurrentFrame.mvpMapPoints[c] or -1; *nmatches = the function's return value.  The reference's
+ *    sequential first-come-first-served behaviour is reproduced exactly. */
+int pslfe_orb_search_by_projection_last(pslfe_frame* cur, int slot, const PslProjQuery* queries, const uint8_t* qdesc,
+                                        int nq, const uint8_t* taken, int check_orientation, int32_t* match,
+                                        int32_t* assigned, int* nmatches);
+/* == ORBmatcher::SearchByProjection(F, vpMapPoints, th) src/ORBmatcher.cc:45-129: best and second
+ *    best in the window, ratio test `nnratio` only when both lie on the same octave (:118-125). */
+int pslfe_orb_search_by_projection_map(pslfe_frame* cur, int slot, const PslProjQuery* queries, const uint8_t* qdesc,
+                                       int nq, const uint8_t* taken, float nnratio, int32_t* match, int32_t* assigned,
+                                       int* nmatches);
+/* Batched, HBM-resident form of pslfe_orb_search_by_projection_last: pair p searches slot
+ * slot0 + p with d_nq[p] queries at d_queries + p*qstride (descriptors at d_qdesc + p*qstride*32),
+ * writes d_match + p*qstride and d_nmatches[p].  Asynchronous on the context's stream. */
+int pslfe_orb_search_by_projection_last_device(pslfe_frame* cur, int slot0, int npairs, const PslProjQuery* d_queries,
+                                               const uint8_t* d_qdesc, const int32_t* d_nq, int qstride,
+                                               int check_orientation, int32_t* d_match, int32_t* d_nmatches);
+
+/* == LSDmatcher::matchNNR add_src/LSDmatcher.cpp:354-376 (and LSDmatcher::match :378-413, whose
+ *    live branch is matchNNR): matches12[i] = best train row if d0 < d1 * nnr (float compare on
+ *    DMatch.distance) else -1; *nmatches = return value.  n2 < 2 is UB in the reference
+ *    (:369); defined here as "no match". */
+int pslfe_line_match_nnr(pslfe_ctx* ctx, const uint8_t* desc1, int n1, const uint8_t* desc2, int n2, float nnr,
+                         int32_t* matches12, int* nmatches);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,239 @@
+// ORACLE — test infrastructure only (see orb_oracle.cpp header). CPU restatement of the
+// descriptor-matching part of the path, written sequentially exactly as the reference runs it:
+//   ORBmatcher::DescriptorDistance            src/ORBmatcher.cc:1647-1663 (SWAR popcount)
+//   Frame::AssignFeaturesToGrid / PosInGrid   src/Frame.cc:269-284, 1040-1050
+//   Frame::GetFeaturesInArea                  src/Frame.cc:985-1038
+//   ORBmatcher::SearchByProjection(cur,last)  src/ORBmatcher.cc:1328-1470 (from the projected
+//        queries on; the 3-D projection itself is host logic of Tracking)
+//   ORBmatcher::SearchByProjection(F,MPs)     src/ORBmatcher.cc:45-129
+//   ORBmatcher::ComputeThreeMaxima            src/ORBmatcher.cc:1601-1645
+//   cv::BFMatcher(NORM_HAMMING).knnMatch(k=2) Appendix A.7; LSDmatcher::matchNNR add_src/LSDmatcher.cpp:354-376
+// PARITY UNPINNED: the reference holds no fixtures for these functions.
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "psl_oracle.h"
+
+namespace {
+
+const int GRID_COLS = 64, GRID_ROWS = 48;  // include/Frame.h:45-46
+const int TH_HIGH = 100, HISTO_LENGTH = 30;
+
+int descriptor_distance(const uint8_t* a, const uint8_t* b) {
+    const int32_t* pa = (const int32_t*)a;
+    const int32_t* pb = (const int32_t*)b;
+    int dist = 0;
+    for (int i = 0; i < 8; i++, pa++, pb++) {
+        unsigned int v = *pa ^ *pb;
+        v = v - ((v >> 1) & 0x55555555);
+        v = (v & 0x33333333) + ((v >> 2) & 0x33333333);
+        dist += (((v + (v >> 4)) & 0xF0F0F0F) * 0x1010101) >> 24;
+    }
+    return dist;
+}
+
+struct Grid {
+    float minX, minY, maxX, maxY, invW, invH;
+    std::vector<int> cell[GRID_COLS][GRID_ROWS];
+    const PsoKeyPoint* kps;
+    int n;
+
+    void build(const PsoKeyPoint* k, int nn, float mnx, float mny, float mxx, float mxy) {
+        kps = k; n = nn; minX = mnx; minY = mny; maxX = mxx; maxY = mxy;
+        invW = static_cast<float>(GRID_COLS) / static_cast<float>(maxX - minX);
+        invH = static_cast<float>(GRID_ROWS) / static_cast<float>(maxY - minY);
+        for (int i = 0; i < n; ++i) {
+            int posX = (int)std::round((k[i].x - minX) * invW);
+            int posY = (int)std::round((k[i].y - minY) * invH);
+            if (posX < 0 || posX >= GRID_COLS || posY < 0 || posY >= GRID_ROWS) continue;
+            cell[posX][posY].push_back(i);
+        }
+    }
+
+    std::vector<int> area(float x, float y, float r, int minLevel, int maxLevel) const {
+        std::vector<int> out;
+        const int nMinCellX = std::max(0, (int)std::floor((x - minX - r) * invW));
+        if (nMinCellX >= GRID_COLS) return out;
+        const int nMaxCellX = std::min(GRID_COLS - 1, (int)std::ceil((x - minX + r) * invW));
+        if (nMaxCellX < 0) return out;
+        const int nMinCellY = std::max(0, (int)std::floor((y - minY - r) * invH));
+        if (nMinCellY >= GRID_ROWS) return out;
+        const int nMaxCellY = std::min(GRID_ROWS - 1, (int)std::ceil((y - minY + r) * invH));
+        if (nMaxCellY < 0) return out;
+        const bool bCheckLevels = (minLevel > 0) || (maxLevel >= 0);
+        for (int ix = nMinCellX; ix <= nMaxCellX; ix++)
+            for (int iy = nMinCellY; iy <= nMaxCellY; iy++)
+                for (int j : cell[ix][iy]) {
+                    const PsoKeyPoint& kp = kps[j];
+                    if (bCheckLevels) {
+                        if (kp.octave < minLevel) continue;
+                        if (maxLevel >= 0 && kp.octave > maxLevel) continue;
+                    }
+                    const float distx = kp.x - x, disty = kp.y - y;
+                    if (std::fabs(distx) < r && std::fabs(disty) < r) out.push_back(j);
+                }
+        return out;
+    }
+};
+
+void three_maxima(const std::vector<int>* histo, int L, int& ind1, int& ind2, int& ind3) {
+    int max1 = 0, max2 = 0, max3 = 0;
+    for (int i = 0; i < L; i++) {
+        const int s = (int)histo[i].size();
+        if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+        else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+        else if (s > max3) { max3 = s; ind3 = i; }
+    }
+    if (max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+    else if (max3 < 0.1f * (float)max1) { ind3 = -1; }
+}
+
+}  // namespace
+
+extern "C" {
+
+int pso_hamming256(const uint8_t* a, const uint8_t* b) { return descriptor_distance(a, b); }
+
+// CSR of the grid in GetFeaturesInArea visiting order (cell = ix*48+iy). start: 3073 ints.
+int pso_grid_build(const PsoKeyPoint* kps, int n, float minX, float minY, float maxX, float maxY, int* start, int* idx) {
+    Grid* g = new Grid();
+    g->build(kps, n, minX, minY, maxX, maxY);
+    int p = 0;
+    for (int ix = 0; ix < GRID_COLS; ++ix)
+        for (int iy = 0; iy < GRID_ROWS; ++iy) {
+            start[ix * GRID_ROWS + iy] = p;
+            for (int j : g->cell[ix][iy]) idx[p++] = j;
+        }
+    start[GRID_COLS * GRID_ROWS] = p;
+    delete g;
+    return p;
+}
+
+int pso_search_by_projection_last(const PsoKeyPoint* kps, const uint8_t* desc, const float* uright, int n, float minX,
+                                  float minY, float maxX, float maxY, const PsoProjQuery* q, const uint8_t* qdesc, int nq,
+                                  const uint8_t* taken, int checkOri, int* match, int* assigned) {
+    Grid* g = new Grid();
+    g->build(kps, n, minX, minY, maxX, maxY);
+    int nmatches = 0;
+    std::vector<int> rotHist[HISTO_LENGTH];
+    const float factor = 1.0f / HISTO_LENGTH;
+    std::vector<int> owner(n, -1);      // CurrentFrame.mvpMapPoints[i2] as a query index
+    std::vector<char> blocked(n, 0);    // mvpMapPoints[i2] && Observations()>0
+    for (int i = 0; i < n; ++i) blocked[i] = taken ? (taken[i] != 0) : 0;
+    std::vector<std::pair<int, int>> histEntries[HISTO_LENGTH];  // (query, keypoint)
+    for (int i = 0; i < nq; ++i) {
+        match[i] = -1;
+        const std::vector<int> cand = g->area(q[i].u, q[i].v, q[i].radius, q[i].min_level, q[i].max_level);
+        if (cand.empty()) continue;
+        int bestDist = 256, bestIdx2 = -1;
+        for (int i2 : cand) {
+            if (blocked[i2]) continue;
+            const float ur_i2 = uright ? uright[i2] : -1.f;
+            if (ur_i2 > 0) {
+                const float er = std::fabs(q[i].ur - ur_i2);
+                if (er > q[i].radius) continue;
+            }
+            const int dist = descriptor_distance(qdesc + (size_t)i * 32, desc + (size_t)i2 * 32);
+            if (dist < bestDist) { bestDist = dist; bestIdx2 = i2; }
+        }
+        if (bestDist <= TH_HIGH) {
+            owner[bestIdx2] = i;
+            blocked[bestIdx2] = q[i].blocks != 0;
+            match[i] = bestIdx2;
+            nmatches++;
+            if (checkOri) {
+                float rot = q[i].angle - kps[bestIdx2].angle;
+                if (rot < 0.0) rot += 360.0f;
+                int bin = (int)std::round(rot * factor);
+                if (bin == HISTO_LENGTH) bin = 0;
+                rotHist[bin].push_back(bestIdx2);
+                histEntries[bin].push_back(std::make_pair(i, bestIdx2));
+            }
+        }
+    }
+    if (checkOri) {
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        three_maxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int b = 0; b < HISTO_LENGTH; b++)
+            if (b != ind1 && b != ind2 && b != ind3)
+                for (auto& e : histEntries[b]) {
+                    owner[e.second] = -1;
+                    match[e.first] = -1;
+                    nmatches--;
+                }
+    }
+    if (assigned) for (int i = 0; i < n; ++i) assigned[i] = owner[i];
+    delete g;
+    return nmatches;
+}
+
+int pso_search_by_projection_map(const PsoKeyPoint* kps, const uint8_t* desc, const float* uright, int n, float minX,
+                                 float minY, float maxX, float maxY, const PsoProjQuery* q, const uint8_t* qdesc, int nq,
+                                 const uint8_t* taken, float nnratio, int* match, int* assigned) {
+    Grid* g = new Grid();
+    g->build(kps, n, minX, minY, maxX, maxY);
+    int nmatches = 0;
+    std::vector<int> owner(n, -1);
+    std::vector<char> blocked(n, 0);
+    for (int i = 0; i < n; ++i) blocked[i] = taken ? (taken[i] != 0) : 0;
+    for (int i = 0; i < nq; ++i) {
+        match[i] = -1;
+        const std::vector<int> cand = g->area(q[i].u, q[i].v, q[i].radius, q[i].min_level, q[i].max_level);
+        if (cand.empty()) continue;
+        int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+        for (int idx : cand) {
+            if (blocked[idx]) continue;
+            const float ur = uright ? uright[idx] : -1.f;
+            if (ur > 0) {
+                const float er = std::fabs(q[i].ur - ur);
+                if (er > q[i].radius) continue;
+            }
+            const int dist = descriptor_distance(qdesc + (size_t)i * 32, desc + (size_t)idx * 32);
+            if (dist < bestDist) {
+                bestDist2 = bestDist; bestDist = dist; bestLevel2 = bestLevel; bestLevel = kps[idx].octave; bestIdx = idx;
+            } else if (dist < bestDist2) {
+                bestLevel2 = kps[idx].octave; bestDist2 = dist;
+            }
+        }
+        if (bestDist <= TH_HIGH) {
+            if (bestLevel == bestLevel2 && bestDist > nnratio * bestDist2) continue;
+            owner[bestIdx] = i;
+            blocked[bestIdx] = q[i].blocks != 0;
+            match[i] = bestIdx;
+            nmatches++;
+        }
+    }
+    if (assigned) for (int i = 0; i < n; ++i) assigned[i] = owner[i];
+    delete g;
+    return nmatches;
+}
+
+// BFMatcher(NORM_HAMMING, crossCheck=false).knnMatch(k=2): ascending distance, lower train index
+// first on ties; missing neighbours = (-1, 0x7fffffff).
+void pso_hamming_knn2(const uint8_t* q, int nq, const uint8_t* t, int nt, int* idx, int* dist) {
+    for (int i = 0; i < nq; ++i) {
+        int b0 = 0x7fffffff, b1 = 0x7fffffff, i0 = -1, i1 = -1;
+        for (int j = 0; j < nt; ++j) {
+            const int d = descriptor_distance(q + (size_t)i * 32, t + (size_t)j * 32);
+            if (d < b0) { b1 = b0; i1 = i0; b0 = d; i0 = j; }
+            else if (d < b1) { b1 = d; i1 = j; }
+        }
+        idx[2 * i] = i0; idx[2 * i + 1] = i1; dist[2 * i] = b0; dist[2 * i + 1] = b1;
+    }
+}
+
+int pso_line_match_nnr(const uint8_t* d1, int n1, const uint8_t* d2, int n2, float nnr, int* matches12) {
+    std::vector<int> idx(2 * (size_t)std::max(n1, 1)), dist(2 * (size_t)std::max(n1, 1));
+    pso_hamming_knn2(d1, n1, d2, n2, idx.data(), dist.data());
+    int matches = 0;
+    for (int i = 0; i < n1; ++i) {
+        matches12[i] = -1;
+        if (n2 < 2) continue;  // reference indexes matches_[idx][1] out of bounds (:369): defined as no match
+        if ((float)dist[2 * i] < (float)dist[2 * i + 1] * nnr) { matches12[i] = idx[2 * i]; matches++; }
+    }
+    return matches;
+}
+
+}  // extern "C"

@@ -25,6 +25,13 @@ typedef struct PsoKeyLine {
     int32_t numOfPixels;
 } PsoKeyLine;
 
+typedef struct PsoProjQuery {
+    float u, v, radius, ur;
+    int32_t min_level, max_level;
+    float angle;
+    int32_t blocks;
+} PsoProjQuery;
+
 void* pso_orb_create(int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST);
 void pso_orb_destroy(void* h);
 int pso_orb_extract(void* h, const uint8_t* gray, int w, int hh, int stride, PsoKeyPoint* kps, uint8_t* desc, int cap);
@@ -49,6 +56,17 @@ float pso_libm_sinf(float x);
 float pso_libm_cosf(float x);
 int pso_cvround_d(double v);
 const int8_t* pso_orb_pattern(void);
+
+int pso_hamming256(const uint8_t* a, const uint8_t* b);
+int pso_grid_build(const PsoKeyPoint* kps, int n, float minX, float minY, float maxX, float maxY, int* start, int* idx);
+int pso_search_by_projection_last(const PsoKeyPoint* kps, const uint8_t* desc, const float* uright, int n, float minX,
+                                  float minY, float maxX, float maxY, const PsoProjQuery* q, const uint8_t* qdesc, int nq,
+                                  const uint8_t* taken, int checkOri, int* match, int* assigned);
+int pso_search_by_projection_map(const PsoKeyPoint* kps, const uint8_t* desc, const float* uright, int n, float minX,
+                                 float minY, float maxX, float maxY, const PsoProjQuery* q, const uint8_t* qdesc, int nq,
+                                 const uint8_t* taken, float nnratio, int* match, int* assigned);
+void pso_hamming_knn2(const uint8_t* q, int nq, const uint8_t* t, int nt, int* idx, int* dist);
+int pso_line_match_nnr(const uint8_t* d1, int n1, const uint8_t* d2, int n2, float nnr, int* matches12);
 
 #ifdef __cplusplus
 }

@@ -245,3 +245,111 @@ class ORBextractor:
             self.close()
         except Exception:
             pass
+
+
+class FrameGrid:
+    """Keypoints of up to `max_frames` frames on the 64x48 grid of include/Frame.h:45-46
+    (== the part of ORB_SLAM2::Frame the matchers read: mvKeysUn, mDescriptors, mvuRight, mGrid)."""
+
+    def __init__(self, max_keypoints, max_frames=1, ctx=None):
+        self.ctx = ctx or default_context()
+        self.cap, self.max_frames = max_keypoints, max_frames
+        self._h = C.c_void_p()
+        _check(lib().pslfe_frame_create(self.ctx._h, C.c_int(max_keypoints), C.c_int(max_frames), C.byref(self._h)),
+               "pslfe_frame_create")
+        self.n = [0] * max_frames
+
+    def set(self, slot, kps, desc, bounds, uright=None):
+        kps = np.ascontiguousarray(kps, KEYPOINT_DTYPE)
+        desc = np.ascontiguousarray(desc, np.uint8)
+        ur = None if uright is None else np.ascontiguousarray(uright, np.float32)
+        _check(lib().pslfe_frame_set(self._h, C.c_int(slot), _ptr(kps), _ptr(desc), _ptr(ur), C.c_int(len(kps)),
+                                     *[C.c_float(b) for b in bounds]), "pslfe_frame_set")
+        self.n[slot] = len(kps)
+
+    def set_from_orb(self, orb, bounds):
+        _check(lib().pslfe_frame_set_from_orb(self._h, orb._h, *[C.c_float(b) for b in bounds]), "pslfe_frame_set_from_orb")
+
+    def debug_grid(self, slot):
+        start = np.zeros(64 * 48 + 1, np.int32)
+        idx = np.zeros(self.cap, np.int32)
+        n = C.c_int()
+        _check(lib().pslfe_frame_debug_grid(self._h, C.c_int(slot), _ptr(start), _ptr(idx), C.c_int(self.cap), C.byref(n)),
+               "pslfe_frame_debug_grid")
+        return start, idx[:n.value]
+
+    def close(self):
+        if self._h:
+            lib().pslfe_frame_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class ORBmatcher:
+    """== ORB_SLAM2::ORBmatcher (include/ORBmatcher.h:36-104), the per-frame projection searches."""
+
+    TH_HIGH, TH_LOW, HISTO_LENGTH = 100, 50, 30
+
+    def __init__(self, nnratio=0.6, checkOri=True):
+        self.mfNNratio, self.mbCheckOrientation = nnratio, checkOri
+
+    def _run(self, fn, frame, slot, queries, qdesc, taken, extra):
+        queries = np.ascontiguousarray(queries, PROJQUERY_DTYPE)
+        qdesc = np.ascontiguousarray(qdesc, np.uint8)
+        nq = len(queries)
+        match = np.full(max(nq, 1), -1, np.int32)
+        assigned = np.full(max(frame.n[slot], 1), -1, np.int32)
+        tk = None if taken is None else np.ascontiguousarray(taken, np.uint8)
+        nm = C.c_int()
+        _check(fn(frame._h, C.c_int(slot), _ptr(queries), _ptr(qdesc), C.c_int(nq), _ptr(tk), extra, _ptr(match),
+                  _ptr(assigned), C.byref(nm)), "pslfe_orb_search_by_projection")
+        return nm.value, match[:nq], assigned[:frame.n[slot]]
+
+    def SearchByProjectionLast(self, frame, slot, queries, qdesc, taken=None):
+        """SearchByProjection(CurrentFrame, LastFrame, th, bMono) src/ORBmatcher.cc:1328."""
+        return self._run(lib().pslfe_orb_search_by_projection_last, frame, slot, queries, qdesc, taken,
+                         C.c_int(1 if self.mbCheckOrientation else 0))
+
+    def SearchByProjectionMap(self, frame, slot, queries, qdesc, taken=None):
+        """SearchByProjection(F, vpMapPoints, th) src/ORBmatcher.cc:45."""
+        return self._run(lib().pslfe_orb_search_by_projection_map, frame, slot, queries, qdesc, taken,
+                         C.c_float(self.mfNNratio))
+
+
+def hamming_knn2(q, t, ctx=None):
+    """cv::BFMatcher(NORM_HAMMING).knnMatch(q, t, 2) -> (idx[nq,2], dist[nq,2])."""
+    ctx = ctx or default_context()
+    q = np.ascontiguousarray(q, np.uint8).reshape(-1, 32)
+    t = np.ascontiguousarray(t, np.uint8).reshape(-1, 32)
+    idx = np.zeros((max(len(q), 1), 2), np.int32)
+    dist = np.zeros((max(len(q), 1), 2), np.int32)
+    _check(lib().pslfe_hamming_knn2(ctx._h, _ptr(q), C.c_int(len(q)), _ptr(t), C.c_int(len(t)), _ptr(idx), _ptr(dist)),
+           "pslfe_hamming_knn2")
+    return idx[:len(q)], dist[:len(q)]
+
+
+class LSDmatcher:
+    """== ORB_SLAM2::LSDmatcher (add_inc/LSDmatcher.h:18-75), descriptor part."""
+
+    TH_HIGH, TH_LOW = 80, 50
+
+    def __init__(self, nnratio=0.95, checkOri=True, ctx=None):
+        self.mfNNratio, self.mbCheckOrientation = nnratio, checkOri
+        self.ctx = ctx or default_context()
+
+    def matchNNR(self, desc1, desc2, nnr):
+        """add_src/LSDmatcher.cpp:354-376 -> (matches, matches_12)."""
+        d1 = np.ascontiguousarray(desc1, np.uint8).reshape(-1, 32)
+        d2 = np.ascontiguousarray(desc2, np.uint8).reshape(-1, 32)
+        m12 = np.full(max(len(d1), 1), -1, np.int32)
+        nm = C.c_int()
+        _check(lib().pslfe_line_match_nnr(self.ctx._h, _ptr(d1), C.c_int(len(d1)), _ptr(d2), C.c_int(len(d2)),
+                                          C.c_float(nnr), _ptr(m12), C.byref(nm)), "pslfe_line_match_nnr")
+        return nm.value, m12[:len(d1)]
+
+    match = matchNNR  # LSDmatcher::match's live branch is matchNNR (:378-413)

@@ -1,0 +1,604 @@
+// libpslfe: descriptor matching on the 64x48 frame grid and brute-force Hamming kNN-2. Product code.
+// Reference behaviour reproduced:
+//   Frame::AssignFeaturesToGrid / PosInGrid / GetFeaturesInArea   src/Frame.cc:269-284, 1040-1050, 985-1038
+//   ORBmatcher::SearchByProjection(cur,last)                      src/ORBmatcher.cc:1328-1470
+//   ORBmatcher::SearchByProjection(F,MPs)                         src/ORBmatcher.cc:45-129
+//   ORBmatcher::ComputeThreeMaxima / DescriptorDistance           src/ORBmatcher.cc:1601-1663
+//   BFMatcher(NORM_HAMMING).knnMatch(k=2) in LSDmatcher::matchNNR  add_src/LSDmatcher.cpp:354-376
+//
+// The reference matchers are sequential: a keypoint taken by a map point with observations is
+// skipped by every LATER query (src/ORBmatcher.cc:1401-1403).  k_window_match reproduces that
+// exactly with a fixpoint: every query picks its best candidate among those not taken by an
+// EARLIER query; "taken by" is recomputed from the current picks until nothing changes.  By
+// induction over the query index the fixpoint is the sequential result.
+#include <string.h>
+
+#include <vector>
+
+#include "pslfe_internal.h"
+#include "psl_device_math.h"
+
+#define PSL_GRID_COLS 64
+#define PSL_GRID_ROWS 48
+#define PSL_GRID_CELLS (PSL_GRID_COLS * PSL_GRID_ROWS)
+#define PSL_QMAX 4096      // most queries / keypoints one workgroup handles
+#define PSL_TH_HIGH 100    // ORBmatcher::TH_HIGH src/ORBmatcher.cc:37
+#define PSL_HISTO 30       // ORBmatcher::HISTO_LENGTH :39
+
+struct FrameMeta {
+    int n;
+    float minX, minY, invW, invH;
+};
+
+struct FrameStore {  // slot s lives at [s * cap] of every array
+    PslKeyPoint* kps;
+    uint8_t* desc;
+    float* uright;
+    uint16_t* cellof;
+    int* gstart;  // [slot][PSL_GRID_CELLS + 1]
+    int* gidx;    // [slot][cap]
+    FrameMeta* meta;
+    int cap;
+};
+
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_frame_import(FrameStore S, const PslKeyPoint* __restrict__ okps,
+                                                       const uint8_t* __restrict__ odesc, const int* __restrict__ ocounts,
+                                                       int ocap, float minX, float minY, float invW, float invH) {
+    const int slot = blockIdx.x;
+    int n = ocounts[slot];
+    n = n < S.cap ? n : S.cap;
+    const uint32_t* sk = reinterpret_cast<const uint32_t*>(okps + (size_t)slot * ocap);
+    uint32_t* dk = reinterpret_cast<uint32_t*>(S.kps + (size_t)slot * S.cap);
+    for (int i = threadIdx.x; i < n * 7; i += 256) dk[i] = sk[i];
+    const uint32_t* sd = reinterpret_cast<const uint32_t*>(odesc + (size_t)slot * ocap * 32);
+    uint32_t* dd = reinterpret_cast<uint32_t*>(S.desc + (size_t)slot * S.cap * 32);
+    for (int i = threadIdx.x; i < n * 8; i += 256) dd[i] = sd[i];
+    float* ur = S.uright + (size_t)slot * S.cap;
+    for (int i = threadIdx.x; i < n; i += 256) ur[i] = -1.f;
+    if (threadIdx.x == 0) {
+        FrameMeta m;
+        m.n = n; m.minX = minX; m.minY = minY; m.invW = invW; m.invH = invH;
+        S.meta[slot] = m;
+    }
+}
+
+// mGrid[ix][iy] as CSR with cell = ix*48+iy (the order GetFeaturesInArea walks), indices ascending
+// inside a cell (push_back order of AssignFeaturesToGrid).
+__global__ __launch_bounds__(1024) void k_build_grid(FrameStore S, int slot0) {
+    __shared__ int s_cnt[PSL_GRID_CELLS];
+    __shared__ int s_w[17];
+    const int slot = slot0 + blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const FrameMeta M = S.meta[slot];
+    const PslKeyPoint* kps = S.kps + (size_t)slot * S.cap;
+    uint16_t* cellof = S.cellof + (size_t)slot * S.cap;
+    int* gstart = S.gstart + (size_t)slot * (PSL_GRID_CELLS + 1);
+    int* gidx = S.gidx + (size_t)slot * S.cap;
+    for (int c = tid; c < PSL_GRID_CELLS; c += 1024) s_cnt[c] = 0;
+    __syncthreads();
+    for (int i = tid; i < M.n; i += 1024) {
+        const int posX = (int)__builtin_roundf(PSL_FMUL(PSL_FSUB(kps[i].x, M.minX), M.invW));  // PosInGrid :1042-1043
+        const int posY = (int)__builtin_roundf(PSL_FMUL(PSL_FSUB(kps[i].y, M.minY), M.invH));
+        const bool ok = posX >= 0 && posX < PSL_GRID_COLS && posY >= 0 && posY < PSL_GRID_ROWS;
+        const int c = ok ? posX * PSL_GRID_ROWS + posY : 0xffff;
+        cellof[i] = (uint16_t)c;
+        if (ok) atomicAdd(&s_cnt[c], 1);
+    }
+    __syncthreads();
+    const int c0 = tid * 3;
+    const int a = s_cnt[c0], b = s_cnt[c0 + 1], c = s_cnt[c0 + 2];
+    int inc = a + b + c;
+    const int mine = inc;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(inc, o); if (lane >= o) inc += u; }
+    if (lane == 63) s_w[wave] = inc;
+    __syncthreads();
+    if (tid == 0) {
+        int acc = 0;
+        for (int k = 0; k < 16; ++k) { const int t = s_w[k]; s_w[k] = acc; acc += t; }
+        s_w[16] = acc;
+    }
+    __syncthreads();
+    const int st = inc - mine + s_w[wave];
+    gstart[c0] = st; gstart[c0 + 1] = st + a; gstart[c0 + 2] = st + a + b;
+    if (tid == 1023) gstart[PSL_GRID_CELLS] = s_w[16];
+    s_cnt[c0] = st; s_cnt[c0 + 1] = st + a; s_cnt[c0 + 2] = st + a + b;  // fill cursors
+    __syncthreads();
+    for (int i = tid; i < M.n; i += 1024) {
+        const int cc = cellof[i];
+        if (cc != 0xffff) gidx[atomicAdd(&s_cnt[cc], 1)] = i;
+    }
+    __syncthreads();
+    // ascending index inside each (tiny) cell run
+    int lo = st;
+    const int len[3] = {a, b, c};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        for (int i = lo + 1; i < lo + len[k]; ++i) {
+            const int v = gidx[i];
+            int j = i - 1;
+            while (j >= lo && gidx[j] > v) { gidx[j + 1] = gidx[j]; --j; }
+            gidx[j + 1] = v;
+        }
+        lo += len[k];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int psl_hamming256(const uint32_t* q, const uint32_t* __restrict__ d) {
+    int s = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s += __popc(q[k] ^ d[k]);
+    return s;
+}
+
+__device__ __forceinline__ void psl_merge2(uint32_t& k1, uint32_t& k2, uint32_t o1, uint32_t o2) {
+    const uint32_t lo = min(k1, o1), hi = max(k1, o1);
+    k2 = min(hi, min(k2, o2));
+    k1 = lo;
+}
+
+struct MatchArgs {
+    FrameStore S;
+    int slot0;
+    const PslProjQuery* q;
+    const uint8_t* qdesc;
+    const int* nq_arr;
+    int nq_single, qstride;
+    const uint8_t* taken;
+    int check_ori;
+    float nnratio;
+    int* match;
+    int* assigned;
+    int* nmatches;
+};
+
+// MODE 0: SearchByProjection(cur,last); MODE 1: SearchByProjection(F, MapPoints).
+// One workgroup (16 waves) per frame; one wave per query at a time; lane l walks grid column
+// nMinCellX + l, whose cells nMinCellY..nMaxCellY are one contiguous CSR run.
+template <int MODE>
+__global__ __launch_bounds__(1024) void k_window_match(MatchArgs A) {
+    __shared__ int s_choice[PSL_QMAX];
+    __shared__ int s_blocker[PSL_QMAX];
+    __shared__ uint8_t s_bin[PSL_QMAX];
+    __shared__ int s_hist[PSL_HISTO];
+    __shared__ int s_ind[3];
+    __shared__ int s_flag[2];  // 0: changed, 1: nmatches
+
+    const int pair = blockIdx.x, slot = A.slot0 + pair, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const FrameStore& S = A.S;
+    const FrameMeta M = S.meta[slot];
+    const PslKeyPoint* kps = S.kps + (size_t)slot * S.cap;
+    const uint32_t* desc = reinterpret_cast<const uint32_t*>(S.desc + (size_t)slot * S.cap * 32);
+    const float* uright = S.uright + (size_t)slot * S.cap;
+    const int* gstart = S.gstart + (size_t)slot * (PSL_GRID_CELLS + 1);
+    const int* gidx = S.gidx + (size_t)slot * S.cap;
+    int nq = A.nq_arr ? A.nq_arr[pair] : A.nq_single;
+    nq = nq < A.qstride ? nq : A.qstride;
+    nq = nq < PSL_QMAX ? nq : PSL_QMAX;
+    const int n = M.n < PSL_QMAX ? M.n : PSL_QMAX;
+    const PslProjQuery* Q = A.q + (size_t)pair * A.qstride;
+    const uint32_t* QD = reinterpret_cast<const uint32_t*>(A.qdesc + (size_t)pair * A.qstride * 32);
+    const uint8_t* taken = A.taken ? A.taken + (size_t)pair * S.cap : nullptr;
+
+    for (int i = tid; i < nq; i += 1024) s_choice[i] = -2;  // -2: not evaluated yet
+    for (int i = tid; i < n; i += 1024) s_blocker[i] = (taken && taken[i]) ? -1 : 0x7fffffff;
+    __syncthreads();
+
+    for (int iter = 0; iter <= nq; ++iter) {
+        if (tid == 0) s_flag[0] = 0;
+        __syncthreads();
+        for (int qi = wave; qi < nq; qi += 16) {
+            const PslProjQuery q = Q[qi];
+            uint32_t qd[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) qd[k] = QD[(size_t)qi * 8 + k];
+            // GetFeaturesInArea window (src/Frame.cc:990-1004)
+            const float r = q.radius;
+            const int minCX = max(0, (int)__builtin_floorf(PSL_FMUL(PSL_FSUB(PSL_FSUB(q.u, M.minX), r), M.invW)));
+            const int maxCX = min(PSL_GRID_COLS - 1, (int)__builtin_ceilf(PSL_FMUL(PSL_FADD(PSL_FSUB(q.u, M.minX), r), M.invW)));
+            const int minCY = max(0, (int)__builtin_floorf(PSL_FMUL(PSL_FSUB(PSL_FSUB(q.v, M.minY), r), M.invH)));
+            const int maxCY = min(PSL_GRID_ROWS - 1, (int)__builtin_ceilf(PSL_FMUL(PSL_FADD(PSL_FSUB(q.v, M.minY), r), M.invH)));
+            uint32_t k1 = 0xffffffffu, k2 = 0xffffffffu;
+            const bool window = minCX < PSL_GRID_COLS && maxCX >= 0 && minCY < PSL_GRID_ROWS && maxCY >= 0;
+            const int ix = minCX + lane;
+            if (window && ix <= maxCX) {
+                const bool checkLevels = (q.min_level > 0) || (q.max_level >= 0);
+                const int p1 = gstart[ix * PSL_GRID_ROWS + maxCY + 1];
+                for (int p = gstart[ix * PSL_GRID_ROWS + minCY]; p < p1; ++p) {
+                    const int i2 = gidx[p];
+                    const PslKeyPoint kp = kps[i2];
+                    if (checkLevels) {
+                        if (kp.octave < q.min_level) continue;
+                        if (q.max_level >= 0 && kp.octave > q.max_level) continue;
+                    }
+                    if (!(__builtin_fabsf(PSL_FSUB(kp.x, q.u)) < r && __builtin_fabsf(PSL_FSUB(kp.y, q.v)) < r)) continue;
+                    if (i2 >= n || s_blocker[i2] < qi) continue;  // taken by an earlier query (:1401-1403)
+                    const float ur = uright[i2];
+                    if (ur > 0 && __builtin_fabsf(PSL_FSUB(q.ur, ur)) > r) continue;  // (:1405-1411)
+                    const uint32_t key = ((uint32_t)psl_hamming256(qd, desc + (size_t)i2 * 8) << 16) | (uint32_t)p;
+                    if (key < k1) { k2 = k1; k1 = key; } else if (key < k2) k2 = key;
+                }
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) psl_merge2(k1, k2, __shfl_xor(k1, o), __shfl_xor(k2, o));
+            int pick = -1;
+            if (k1 != 0xffffffffu) {
+                const int bestDist = (int)(k1 >> 16), bestIdx = gidx[k1 & 0xffff];
+                bool ok = bestDist <= PSL_TH_HIGH;
+                if (MODE == 1 && ok && k2 != 0xffffffffu) {
+                    const int bestDist2 = (int)(k2 >> 16);
+                    const int l1 = kps[bestIdx].octave, l2 = kps[gidx[k2 & 0xffff]].octave;
+                    if (l1 == l2 && (float)bestDist > PSL_FMUL(A.nnratio, (float)bestDist2)) ok = false;  // (:118-121)
+                }
+                if (ok) pick = bestIdx;
+            }
+            if (lane == 0 && s_choice[qi] != pick) { s_choice[qi] = pick; s_flag[0] = 1; }
+        }
+        __syncthreads();
+        const int changed = s_flag[0];
+        __syncthreads();
+        if (!changed) break;
+        for (int i = tid; i < n; i += 1024) s_blocker[i] = (taken && taken[i]) ? -1 : 0x7fffffff;
+        __syncthreads();
+        for (int qi = tid; qi < nq; qi += 1024) {
+            const int c = s_choice[qi];
+            if (c >= 0 && Q[qi].blocks) atomicMin(&s_blocker[c], qi);
+        }
+        __syncthreads();
+    }
+
+    // rotation consistency (:1431-1467)
+    if (tid < PSL_HISTO) s_hist[tid] = 0;
+    if (tid == 0) { s_ind[0] = s_ind[1] = s_ind[2] = -1; s_flag[1] = 0; }
+    __syncthreads();
+    const bool ori = MODE == 0 && A.check_ori;
+    if (ori) {
+        const float factor = 1.0f / PSL_HISTO;
+        for (int qi = tid; qi < nq; qi += 1024) {
+            const int c = s_choice[qi];
+            if (c < 0) continue;
+            float rot = PSL_FSUB(Q[qi].angle, kps[c].angle);
+            if (rot < 0.0f) rot = PSL_FADD(rot, 360.0f);
+            int bin = (int)__builtin_roundf(PSL_FMUL(rot, factor));
+            if (bin == PSL_HISTO) bin = 0;
+            bin = bin < 0 ? 0 : (bin >= PSL_HISTO ? PSL_HISTO - 1 : bin);
+            s_bin[qi] = (uint8_t)bin;
+            atomicAdd(&s_hist[bin], 1);
+        }
+        __syncthreads();
+        if (tid == 0) {  // ComputeThreeMaxima (:1601-1645)
+            int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
+            for (int i = 0; i < PSL_HISTO; ++i) {
+                const int s = s_hist[i];
+                if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+                else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+                else if (s > max3) { max3 = s; ind3 = i; }
+            }
+            if ((float)max2 < PSL_FMUL(0.1f, (float)max1)) { ind2 = -1; ind3 = -1; }
+            else if ((float)max3 < PSL_FMUL(0.1f, (float)max1)) { ind3 = -1; }
+            s_ind[0] = ind1; s_ind[1] = ind2; s_ind[2] = ind3;
+        }
+        __syncthreads();
+    }
+    // owners: the last query that assigned a keypoint, unless one of its assignments was filtered
+    for (int i = tid; i < n; i += 1024) s_blocker[i] = -1;
+    __syncthreads();
+    int local = 0;
+    int* match = A.match + (size_t)pair * A.qstride;
+    for (int qi = tid; qi < nq; qi += 1024) {
+        const int c = s_choice[qi];
+        bool good = c >= 0;
+        if (good) atomicMax(&s_blocker[c], qi);
+        if (good && ori) { const int b = s_bin[qi]; good = (b == s_ind[0] || b == s_ind[1] || b == s_ind[2]); }
+        match[qi] = good ? c : -1;
+        local += good;
+    }
+    __syncthreads();
+    if (ori)
+        for (int qi = tid; qi < nq; qi += 1024) {
+            const int c = s_choice[qi];
+            if (c < 0) continue;
+            const int b = s_bin[qi];
+            if (!(b == s_ind[0] || b == s_ind[1] || b == s_ind[2])) s_blocker[c] = -1;
+        }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) local += __shfl_xor(local, o);
+    if (lane == 0 && local) atomicAdd(&s_flag[1], local);
+    __syncthreads();
+    if (A.assigned) {
+        int* asg = A.assigned + (size_t)pair * S.cap;
+        for (int i = tid; i < M.n; i += 1024) asg[i] = i < n ? s_blocker[i] : -1;
+    }
+    if (tid == 0) A.nmatches[pair] = s_flag[1];
+}
+
+// BFMatcher(NORM_HAMMING).knnMatch(k = 2): one wave per query row, lanes stride the train rows.
+__global__ __launch_bounds__(256) void k_hamming_knn2(const uint8_t* __restrict__ q, int nq, const uint8_t* __restrict__ t, int nt,
+                                                       int* __restrict__ idx, int* __restrict__ dist) {
+    const int qi = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (qi >= nq) return;
+    uint32_t qd[8];
+    const uint32_t* Q = reinterpret_cast<const uint32_t*>(q) + (size_t)qi * 8;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) qd[k] = Q[k];
+    const uint32_t* T = reinterpret_cast<const uint32_t*>(t);
+    uint32_t k1 = 0xffffffffu, k2 = 0xffffffffu;
+    for (int j = lane; j < nt; j += 64) {
+        const uint32_t key = ((uint32_t)psl_hamming256(qd, T + (size_t)j * 8) << 20) | (uint32_t)j;  // nt < 2^20
+        if (key < k1) { k2 = k1; k1 = key; } else if (key < k2) k2 = key;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) psl_merge2(k1, k2, __shfl_xor(k1, o), __shfl_xor(k2, o));
+    if (lane == 0) {
+        idx[2 * qi] = k1 == 0xffffffffu ? -1 : (int)(k1 & 0xfffff);
+        dist[2 * qi] = k1 == 0xffffffffu ? 0x7fffffff : (int)(k1 >> 20);
+        idx[2 * qi + 1] = k2 == 0xffffffffu ? -1 : (int)(k2 & 0xfffff);
+        dist[2 * qi + 1] = k2 == 0xffffffffu ? 0x7fffffff : (int)(k2 >> 20);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+struct pslfe_frame {
+    pslfe_ctx* ctx = nullptr;
+    int cap = 0, max_frames = 0;
+    FrameStore S = {};
+    // scratch for the host-pointer entry points
+    PslProjQuery* d_q = nullptr;
+    uint8_t* d_qdesc = nullptr;
+    uint8_t* d_taken = nullptr;
+    int* d_match = nullptr;
+    int* d_assigned = nullptr;
+    int* d_nm = nullptr;
+    std::vector<char> slot_set;
+};
+
+int pslfe_orb_internal_last(pslfe_orb* orb, const PslKeyPoint** kps, const uint8_t** desc, const int** counts, int* cap,
+                            int* nframes, pslfe_ctx** ctx);
+
+namespace {
+int host_search(pslfe_frame* f, int slot, const PslProjQuery* queries, const uint8_t* qdesc, int nq, const uint8_t* taken,
+                int mode, int check_ori, float nnratio, int32_t* match, int32_t* assigned, int* nmatches) {
+    PSL_REQUIRE(f && nmatches && (nq == 0 || (queries && qdesc && match)), PSLFE_E_INVALID, "search_by_projection: NULL argument");
+    PSL_REQUIRE(slot >= 0 && slot < f->max_frames && f->slot_set[slot], PSLFE_E_STATE, "search_by_projection: slot %d not set", slot);
+    PSL_REQUIRE(nq >= 0 && nq <= PSL_QMAX, PSLFE_E_INVALID, "search_by_projection: %d queries (max %d)", nq, PSL_QMAX);
+    *nmatches = 0;
+    if (nq == 0) return PSLFE_OK;
+    PSL_HIP(hipSetDevice(f->ctx->device));
+    hipStream_t st = f->ctx->stream;
+    PSL_HIP(hipMemcpyAsync(f->d_q, queries, (size_t)nq * sizeof(PslProjQuery), hipMemcpyHostToDevice, st));
+    PSL_HIP(hipMemcpyAsync(f->d_qdesc, qdesc, (size_t)nq * 32, hipMemcpyHostToDevice, st));
+    FrameMeta m;
+    PSL_HIP(hipMemcpyAsync(&m, f->S.meta + slot, sizeof(m), hipMemcpyDeviceToHost, st));
+    PSL_HIP(hipStreamSynchronize(st));
+    if (taken) PSL_HIP(hipMemcpyAsync(f->d_taken, taken, (size_t)m.n, hipMemcpyHostToDevice, st));
+    MatchArgs A;
+    A.S = f->S;
+    // host calls address exactly one slot; scratch arrays are indexed as "pair 0"
+    A.slot0 = slot; A.q = f->d_q; A.qdesc = f->d_qdesc; A.nq_arr = nullptr; A.nq_single = nq; A.qstride = PSL_QMAX;
+    A.taken = taken ? f->d_taken : nullptr; A.check_ori = check_ori; A.nnratio = nnratio;
+    A.match = f->d_match; A.assigned = f->d_assigned; A.nmatches = f->d_nm;
+    {
+        PSL_STAGE_BEGIN(f->ctx, "match.window");
+        if (mode == 0) k_window_match<0><<<1, 1024, 0, st>>>(A); else k_window_match<1><<<1, 1024, 0, st>>>(A);
+        PSL_STAGE_END(f->ctx, "match.window");
+    }
+    PSL_HIP(hipGetLastError());
+    PSL_HIP(hipMemcpyAsync(match, f->d_match, (size_t)nq * sizeof(int), hipMemcpyDeviceToHost, st));
+    if (assigned && m.n > 0) PSL_HIP(hipMemcpyAsync(assigned, f->d_assigned, (size_t)m.n * sizeof(int), hipMemcpyDeviceToHost, st));
+    PSL_HIP(hipMemcpyAsync(nmatches, f->d_nm, sizeof(int), hipMemcpyDeviceToHost, st));
+    PSL_HIP(hipStreamSynchronize(st));
+    return PSLFE_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int pslfe_frame_create(pslfe_ctx* ctx, int max_keypoints, int max_frames, pslfe_frame** out) {
+    PSL_REQUIRE(ctx && out, PSLFE_E_INVALID, "pslfe_frame_create: NULL argument");
+    *out = nullptr;
+    PSL_REQUIRE(max_keypoints >= 1 && max_keypoints <= PSL_QMAX && max_frames >= 1, PSLFE_E_INVALID,
+                "pslfe_frame_create: max_keypoints %d (1..%d), max_frames %d", max_keypoints, PSL_QMAX, max_frames);
+    PSL_HIP(hipSetDevice(ctx->device));
+    pslfe_frame* f = new pslfe_frame();
+    f->ctx = ctx; f->cap = max_keypoints; f->max_frames = max_frames;
+    f->slot_set.assign(max_frames, 0);
+    const size_t F = (size_t)max_frames, K = (size_t)max_keypoints;
+    f->S.cap = max_keypoints;
+    hipError_t e = hipSuccess;
+    auto A = [&](void** p, size_t bytes) { if (e == hipSuccess) e = hipMalloc(p, bytes ? bytes : 1); };
+    A((void**)&f->S.kps, F * K * sizeof(PslKeyPoint));
+    A((void**)&f->S.desc, F * K * 32);
+    A((void**)&f->S.uright, F * K * sizeof(float));
+    A((void**)&f->S.cellof, F * K * sizeof(uint16_t));
+    A((void**)&f->S.gstart, F * (PSL_GRID_CELLS + 1) * sizeof(int));
+    A((void**)&f->S.gidx, F * K * sizeof(int));
+    A((void**)&f->S.meta, F * sizeof(FrameMeta));
+    A((void**)&f->d_q, PSL_QMAX * sizeof(PslProjQuery));
+    A((void**)&f->d_qdesc, PSL_QMAX * 32);
+    A((void**)&f->d_taken, K);
+    A((void**)&f->d_match, PSL_QMAX * sizeof(int));
+    A((void**)&f->d_assigned, K * sizeof(int));
+    A((void**)&f->d_nm, sizeof(int));
+    if (e != hipSuccess) {
+        pslfe_set_error("pslfe_frame_create: hipMalloc failed: %s", hipGetErrorString(e));
+        pslfe_frame_destroy(f);
+        return PSLFE_E_HIP;
+    }
+    e = hipMemset(f->S.meta, 0, F * sizeof(FrameMeta));
+    *out = f;
+    return PSLFE_OK;
+}
+
+void pslfe_frame_destroy(pslfe_frame* f) {
+    if (!f) return;
+    hipSetDevice(f->ctx->device);
+    hipStreamSynchronize(f->ctx->stream);
+    hipFree(f->S.kps); hipFree(f->S.desc); hipFree(f->S.uright); hipFree(f->S.cellof); hipFree(f->S.gstart);
+    hipFree(f->S.gidx); hipFree(f->S.meta); hipFree(f->d_q); hipFree(f->d_qdesc); hipFree(f->d_taken);
+    hipFree(f->d_match); hipFree(f->d_assigned); hipFree(f->d_nm);
+    delete f;
+}
+
+int pslfe_frame_set(pslfe_frame* f, int slot, const PslKeyPoint* kps, const uint8_t* desc, const float* uright, int n,
+                    float min_x, float min_y, float max_x, float max_y) {
+    PSL_REQUIRE(f && (n == 0 || (kps && desc)), PSLFE_E_INVALID, "pslfe_frame_set: NULL argument");
+    PSL_REQUIRE(slot >= 0 && slot < f->max_frames, PSLFE_E_INVALID, "pslfe_frame_set: slot %d of %d", slot, f->max_frames);
+    PSL_REQUIRE(n >= 0 && n <= f->cap, PSLFE_E_CAPACITY, "pslfe_frame_set: %d keypoints, capacity %d", n, f->cap);
+    PSL_REQUIRE(max_x > min_x && max_y > min_y, PSLFE_E_INVALID, "pslfe_frame_set: empty image bounds");
+    PSL_HIP(hipSetDevice(f->ctx->device));
+    hipStream_t st = f->ctx->stream;
+    const size_t o = (size_t)slot * f->cap;
+    std::vector<float> ur(n > 0 ? n : 1, -1.f);
+    if (n > 0) {
+        PSL_HIP(hipMemcpyAsync(f->S.kps + o, kps, (size_t)n * sizeof(PslKeyPoint), hipMemcpyHostToDevice, st));
+        PSL_HIP(hipMemcpyAsync(f->S.desc + o * 32, desc, (size_t)n * 32, hipMemcpyHostToDevice, st));
+        PSL_HIP(hipMemcpyAsync(f->S.uright + o, uright ? uright : ur.data(), (size_t)n * sizeof(float), hipMemcpyHostToDevice, st));
+    }
+    FrameMeta m;
+    m.n = n; m.minX = min_x; m.minY = min_y;
+    m.invW = (float)PSL_GRID_COLS / (float)(max_x - min_x);  // src/Frame.cc:163-164
+    m.invH = (float)PSL_GRID_ROWS / (float)(max_y - min_y);
+    PSL_HIP(hipMemcpyAsync(f->S.meta + slot, &m, sizeof(m), hipMemcpyHostToDevice, st));
+    PSL_HIP(hipStreamSynchronize(st));  // host staging buffers go out of scope
+    {
+        PSL_STAGE_BEGIN(f->ctx, "match.grid");
+        k_build_grid<<<1, 1024, 0, st>>>(f->S, slot);
+        PSL_STAGE_END(f->ctx, "match.grid");
+    }
+    PSL_HIP(hipGetLastError());
+    f->slot_set[slot] = 1;
+    return PSLFE_OK;
+}
+
+int pslfe_frame_set_from_orb(pslfe_frame* f, pslfe_orb* orb, float min_x, float min_y, float max_x, float max_y) {
+    PSL_REQUIRE(f && orb, PSLFE_E_INVALID, "pslfe_frame_set_from_orb: NULL argument");
+    PSL_REQUIRE(max_x > min_x && max_y > min_y, PSLFE_E_INVALID, "pslfe_frame_set_from_orb: empty image bounds");
+    const PslKeyPoint* okps; const uint8_t* odesc; const int* ocnt; int ocap, nframes; pslfe_ctx* octx;
+    int rc = pslfe_orb_internal_last(orb, &okps, &odesc, &ocnt, &ocap, &nframes, &octx);
+    if (rc) return rc;
+    PSL_REQUIRE(octx == f->ctx, PSLFE_E_INVALID, "pslfe_frame_set_from_orb: handles belong to different contexts");
+    PSL_REQUIRE(nframes <= f->max_frames, PSLFE_E_CAPACITY, "pslfe_frame_set_from_orb: %d frames, %d slots", nframes, f->max_frames);
+    PSL_REQUIRE(ocap <= f->cap, PSLFE_E_CAPACITY, "pslfe_frame_set_from_orb: extractor capacity %d > frame capacity %d", ocap, f->cap);
+    PSL_HIP(hipSetDevice(f->ctx->device));
+    hipStream_t st = f->ctx->stream;
+    const float invW = (float)PSL_GRID_COLS / (float)(max_x - min_x), invH = (float)PSL_GRID_ROWS / (float)(max_y - min_y);
+    {
+        PSL_STAGE_BEGIN(f->ctx, "match.grid");
+        k_frame_import<<<nframes, 256, 0, st>>>(f->S, okps, odesc, ocnt, ocap, min_x, min_y, invW, invH);
+        k_build_grid<<<nframes, 1024, 0, st>>>(f->S, 0);
+        PSL_STAGE_END(f->ctx, "match.grid");
+    }
+    PSL_HIP(hipGetLastError());
+    for (int s = 0; s < nframes; ++s) f->slot_set[s] = 1;
+    return PSLFE_OK;
+}
+
+int pslfe_frame_debug_grid(pslfe_frame* f, int slot, int32_t* start, int32_t* idx, int cap, int* n) {
+    PSL_REQUIRE(f && start && n, PSLFE_E_INVALID, "pslfe_frame_debug_grid: NULL argument");
+    PSL_REQUIRE(slot >= 0 && slot < f->max_frames && f->slot_set[slot], PSLFE_E_STATE, "pslfe_frame_debug_grid: slot %d not set", slot);
+    PSL_HIP(hipSetDevice(f->ctx->device));
+    PSL_HIP(hipStreamSynchronize(f->ctx->stream));
+    PSL_HIP(hipMemcpy(start, f->S.gstart + (size_t)slot * (PSL_GRID_CELLS + 1), (PSL_GRID_CELLS + 1) * sizeof(int), hipMemcpyDeviceToHost));
+    *n = start[PSL_GRID_CELLS];
+    PSL_REQUIRE(*n <= cap, PSLFE_E_CAPACITY, "pslfe_frame_debug_grid: %d entries, capacity %d", *n, cap);
+    if (idx && *n > 0) PSL_HIP(hipMemcpy(idx, f->S.gidx + (size_t)slot * f->cap, (size_t)*n * sizeof(int), hipMemcpyDeviceToHost));
+    return PSLFE_OK;
+}
+
+int pslfe_orb_search_by_projection_last(pslfe_frame* cur, int slot, const PslProjQuery* queries, const uint8_t* qdesc, int nq,
+                                        const uint8_t* taken, int check_orientation, int32_t* match, int32_t* assigned, int* nmatches) {
+    return host_search(cur, slot, queries, qdesc, nq, taken, 0, check_orientation, 0.f, match, assigned, nmatches);
+}
+
+int pslfe_orb_search_by_projection_map(pslfe_frame* cur, int slot, const PslProjQuery* queries, const uint8_t* qdesc, int nq,
+                                       const uint8_t* taken, float nnratio, int32_t* match, int32_t* assigned, int* nmatches) {
+    return host_search(cur, slot, queries, qdesc, nq, taken, 1, 0, nnratio, match, assigned, nmatches);
+}
+
+int pslfe_orb_search_by_projection_last_device(pslfe_frame* cur, int slot0, int npairs, const PslProjQuery* d_queries,
+                                               const uint8_t* d_qdesc, const int32_t* d_nq, int qstride, int check_orientation,
+                                               int32_t* d_match, int32_t* d_nmatches) {
+    PSL_REQUIRE(cur && d_queries && d_qdesc && d_nq && d_match && d_nmatches, PSLFE_E_INVALID, "search_by_projection_last_device: NULL argument");
+    PSL_REQUIRE(npairs >= 1 && slot0 >= 0 && slot0 + npairs <= cur->max_frames && qstride >= 1, PSLFE_E_INVALID,
+                "search_by_projection_last_device: slots %d..%d of %d", slot0, slot0 + npairs - 1, cur->max_frames);
+    for (int s = slot0; s < slot0 + npairs; ++s)
+        PSL_REQUIRE(cur->slot_set[s], PSLFE_E_STATE, "search_by_projection_last_device: slot %d not set", s);
+    PSL_HIP(hipSetDevice(cur->ctx->device));
+    MatchArgs A;
+    A.S = cur->S; A.slot0 = slot0; A.q = d_queries; A.qdesc = d_qdesc; A.nq_arr = d_nq; A.nq_single = 0; A.qstride = qstride;
+    A.taken = nullptr; A.check_ori = check_orientation; A.nnratio = 0.f; A.match = d_match; A.assigned = nullptr; A.nmatches = d_nmatches;
+    {
+        PSL_STAGE_BEGIN(cur->ctx, "match.window");
+        k_window_match<0><<<npairs, 1024, 0, cur->ctx->stream>>>(A);
+        PSL_STAGE_END(cur->ctx, "match.window");
+    }
+    PSL_HIP(hipGetLastError());
+    return PSLFE_OK;
+}
+
+int pslfe_hamming_knn2_device(pslfe_ctx* ctx, const uint8_t* d_q, int nq, const uint8_t* d_t, int nt, int32_t* d_idx, int32_t* d_dist) {
+    PSL_REQUIRE(ctx && d_idx && d_dist, PSLFE_E_INVALID, "pslfe_hamming_knn2_device: NULL argument");
+    PSL_REQUIRE(nq >= 0 && nt >= 0 && nt < (1 << 20), PSLFE_E_INVALID, "pslfe_hamming_knn2_device: nq %d nt %d", nq, nt);
+    if (nq == 0) return PSLFE_OK;
+    PSL_REQUIRE(d_q && (nt == 0 || d_t), PSLFE_E_INVALID, "pslfe_hamming_knn2_device: NULL descriptors");
+    PSL_HIP(hipSetDevice(ctx->device));
+    {
+        PSL_STAGE_BEGIN(ctx, "match.knn2");
+        k_hamming_knn2<<<(nq + 3) / 4, 256, 0, ctx->stream>>>(d_q, nq, d_t, nt, d_idx, d_dist);
+        PSL_STAGE_END(ctx, "match.knn2");
+    }
+    PSL_HIP(hipGetLastError());
+    return PSLFE_OK;
+}
+
+int pslfe_hamming_knn2(pslfe_ctx* ctx, const uint8_t* q, int nq, const uint8_t* t, int nt, int32_t* idx, int32_t* dist) {
+    PSL_REQUIRE(ctx && idx && dist, PSLFE_E_INVALID, "pslfe_hamming_knn2: NULL argument");
+    PSL_REQUIRE(nq >= 0 && nt >= 0 && nt < (1 << 20), PSLFE_E_INVALID, "pslfe_hamming_knn2: nq %d nt %d", nq, nt);
+    if (nq == 0) return PSLFE_OK;
+    PSL_REQUIRE(q && (nt == 0 || t), PSLFE_E_INVALID, "pslfe_hamming_knn2: NULL descriptors");
+    PSL_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    uint8_t *dq = nullptr, *dt = nullptr;
+    int *di = nullptr, *dd = nullptr;
+    hipError_t e = hipMalloc((void**)&dq, (size_t)nq * 32);
+    if (e == hipSuccess) e = hipMalloc((void**)&dt, nt ? (size_t)nt * 32 : 1);
+    if (e == hipSuccess) e = hipMalloc((void**)&di, (size_t)nq * 2 * sizeof(int));
+    if (e == hipSuccess) e = hipMalloc((void**)&dd, (size_t)nq * 2 * sizeof(int));
+    int rc = PSLFE_OK;
+    if (e != hipSuccess) { pslfe_set_error("pslfe_hamming_knn2: hipMalloc: %s", hipGetErrorString(e)); rc = PSLFE_E_HIP; }
+    if (!rc) {
+        e = hipMemcpyAsync(dq, q, (size_t)nq * 32, hipMemcpyHostToDevice, st);
+        if (e == hipSuccess && nt) e = hipMemcpyAsync(dt, t, (size_t)nt * 32, hipMemcpyHostToDevice, st);
+        if (e != hipSuccess) { pslfe_set_error("pslfe_hamming_knn2: H2D: %s", hipGetErrorString(e)); rc = PSLFE_E_HIP; }
+    }
+    if (!rc) rc = pslfe_hamming_knn2_device(ctx, dq, nq, dt, nt, di, dd);
+    if (!rc) {
+        e = hipMemcpyAsync(idx, di, (size_t)nq * 2 * sizeof(int), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(dist, dd, (size_t)nq * 2 * sizeof(int), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) { pslfe_set_error("pslfe_hamming_knn2: D2H: %s", hipGetErrorString(e)); rc = PSLFE_E_HIP; }
+    }
+    hipFree(dq); hipFree(dt); hipFree(di); hipFree(dd);
+    return rc;
+}
+
+int pslfe_line_match_nnr(pslfe_ctx* ctx, const uint8_t* desc1, int n1, const uint8_t* desc2, int n2, float nnr,
+                         int32_t* matches12, int* nmatches) {
+    PSL_REQUIRE(ctx && nmatches && (n1 == 0 || matches12), PSLFE_E_INVALID, "pslfe_line_match_nnr: NULL argument");
+    *nmatches = 0;
+    if (n1 <= 0) return PSLFE_OK;
+    std::vector<int> idx((size_t)n1 * 2), dist((size_t)n1 * 2);
+    int rc = pslfe_hamming_knn2(ctx, desc1, n1, desc2, n2, idx.data(), dist.data());
+    if (rc) return rc;
+    int m = 0;
+    for (int i = 0; i < n1; ++i) {
+        matches12[i] = -1;
+        if (n2 < 2) continue;  // reference reads matches_[idx][1] out of bounds (:369): defined as no match
+        if ((float)dist[2 * i] < (float)dist[2 * i + 1] * nnr) { matches12[i] = idx[2 * i]; ++m; }  // (:369)
+    }
+    *nmatches = m;
+    return PSLFE_OK;
+}
+
+}  // extern "C"

@@ -268,6 +268,15 @@ struct pslfe_orb {
     }
 };
 
+// internal view of the last batch for pslfe_match.hip (pslfe_frame_set_from_orb)
+int pslfe_orb_internal_last(pslfe_orb* orb, const PslKeyPoint** kps, const uint8_t** desc, const int** counts, int* cap,
+                            int* nframes, pslfe_ctx** ctx) {
+    PSL_REQUIRE(orb->last_nframes > 0, PSLFE_E_STATE, "no batch extracted yet");
+    *kps = orb->d_kps; *desc = orb->d_desc; *counts = orb->d_counts; *cap = orb->P.out_cap; *nframes = orb->last_nframes;
+    *ctx = orb->ctx;
+    return PSLFE_OK;
+}
+
 extern "C" {
 
 int pslfe_orb_create(pslfe_ctx* ctx, int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST,

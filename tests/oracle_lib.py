@@ -107,3 +107,75 @@ class OracleORB:
             self.L.pso_orb_destroy(self.h)
         except Exception:
             pass
+
+
+PROJQUERY_DTYPE = np.dtype([("u", "<f4"), ("v", "<f4"), ("radius", "<f4"), ("ur", "<f4"), ("min_level", "<i4"),
+                            ("max_level", "<i4"), ("angle", "<f4"), ("blocks", "<i4")])
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def grid_build(kps, bounds):
+    L = load()
+    kps = np.ascontiguousarray(kps, KEYPOINT_DTYPE)
+    start = np.zeros(64 * 48 + 1, np.int32)
+    idx = np.zeros(max(len(kps), 1), np.int32)
+    L.pso_grid_build.argtypes = [C.c_void_p, C.c_int] + [C.c_float] * 4 + [C.c_void_p, C.c_void_p]
+    n = L.pso_grid_build(_p(kps), len(kps), *bounds, _p(start), _p(idx))
+    return start, idx[:n]
+
+
+def _search(fn_name, kps, desc, uright, bounds, queries, qdesc, taken, extra_type, extra):
+    L = load()
+    fn = getattr(L, fn_name)
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int] + [C.c_float] * 4 + [C.c_void_p, C.c_void_p, C.c_int,
+                                                                                     C.c_void_p, extra_type, C.c_void_p, C.c_void_p]
+    kps = np.ascontiguousarray(kps, KEYPOINT_DTYPE)
+    desc = np.ascontiguousarray(desc, np.uint8)
+    queries = np.ascontiguousarray(queries, PROJQUERY_DTYPE)
+    qdesc = np.ascontiguousarray(qdesc, np.uint8)
+    ur = None if uright is None else np.ascontiguousarray(uright, np.float32)
+    tk = None if taken is None else np.ascontiguousarray(taken, np.uint8)
+    match = np.full(max(len(queries), 1), -1, np.int32)
+    assigned = np.full(max(len(kps), 1), -1, np.int32)
+    nm = fn(_p(kps), _p(desc), _p(ur), len(kps), *bounds, _p(queries), _p(qdesc), len(queries), _p(tk), extra, _p(match), _p(assigned))
+    return nm, match[:len(queries)], assigned[:len(kps)]
+
+
+def search_by_projection_last(kps, desc, uright, bounds, queries, qdesc, taken, check_ori):
+    return _search("pso_search_by_projection_last", kps, desc, uright, bounds, queries, qdesc, taken, C.c_int, int(check_ori))
+
+
+def search_by_projection_map(kps, desc, uright, bounds, queries, qdesc, taken, nnratio):
+    return _search("pso_search_by_projection_map", kps, desc, uright, bounds, queries, qdesc, taken, C.c_float, float(nnratio))
+
+
+def hamming_knn2(q, t):
+    L = load()
+    q = np.ascontiguousarray(q, np.uint8).reshape(-1, 32)
+    t = np.ascontiguousarray(t, np.uint8).reshape(-1, 32)
+    idx = np.zeros((max(len(q), 1), 2), np.int32)
+    dist = np.zeros((max(len(q), 1), 2), np.int32)
+    L.pso_hamming_knn2.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    L.pso_hamming_knn2(_p(q), len(q), _p(t), len(t), _p(idx), _p(dist))
+    return idx[:len(q)], dist[:len(q)]
+
+
+def line_match_nnr(d1, d2, nnr):
+    L = load()
+    d1 = np.ascontiguousarray(d1, np.uint8).reshape(-1, 32)
+    d2 = np.ascontiguousarray(d2, np.uint8).reshape(-1, 32)
+    m12 = np.full(max(len(d1), 1), -1, np.int32)
+    L.pso_line_match_nnr.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_void_p]
+    n = L.pso_line_match_nnr(_p(d1), len(d1), _p(d2), len(d2), nnr, _p(m12))
+    return n, m12[:len(d1)]
+
+
+def hamming256(a, b):
+    L = load()
+    L.pso_hamming256.argtypes = [C.c_void_p, C.c_void_p]
+    a = np.ascontiguousarray(a, np.uint8)
+    b = np.ascontiguousarray(b, np.uint8)
+    return L.pso_hamming256(_p(a), _p(b))
