@@ -1,0 +1,257 @@
+#!/usr/bin/env python3
+"""bench.py — frames/sec of the PSL-SLAM per-frame feature front-end on MI355X.
+
+A "step" = one pass of the hot path over one batch of B synthetic 640x480 frames that are already
+resident in HBM: ORB extraction (pyramid, per-cell FAST, octree distribution, orientation, blur,
+rBRIEF) of all B frames + frame grid + ORBmatcher::SearchByProjection(cur,last) of every frame
+against its predecessor (BASELINE.json configs[1]: "640x480 synthetic RGB-D stream, ORB-only
+extract+match, 1xMI355X").  Results stay in HBM; with N > 1 every rank runs its own independent
+stream (weak scaling) and the per-frame result records are all-gathered over RCCL.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line (contract in the task statement), including
+  roofline     for the dominant kernel: algorithmic bytes per launch / mean launch time (HIP events
+               on the launch stream over the timed region) vs the 8 TB/s HBM peak
+  cpu_baseline the CPU oracle (oracle/, kind "port": the reference itself cannot be built here)
+               timed single-threaded on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+W, H = 640, 480
+NFEATURES, SCALE, NLEVELS, INI_TH, MIN_TH = 1000, 1.2, 8, 20, 7
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+# ALGORITHMIC bytes per frame, SURVEY.md §8(d) / BASELINE.md §3 (640x480, N = 1000, P = 950 532 px):
+#   gray read WH + pyramid write P-WH + pyramid read P + blurred write P + sampling 512N + outputs 60N
+P_PIX, WH = 950532, W * H
+ORB_BYTES_PER_FRAME = WH + (P_PIX - WH) + P_PIX + P_PIX + 512 * NFEATURES + 60 * NFEATURES  # 3 423 596
+MATCH_BYTES_PER_FRAME = 2 * 32 * NFEATURES + 8 * NFEATURES                                   # 72 000
+# per-kernel shares of that accounting: what each kernel must move at least
+STAGE_BYTES_PER_FRAME = {
+    "orb.pyramid": WH + (P_PIX - WH),        # read level 0, write levels 1..7
+    "orb.fast": P_PIX,                       # read every level once
+    "orb.octree": 8 * 4000,                  # candidate list in + out (~4 k candidates x 8 B); not in §8(d)
+    "orb.blur": P_PIX + P_PIX,               # read every level, write its blurred copy
+    "orb.describe": 512 * NFEATURES + 60 * NFEATURES,
+    "match.grid": 2 * 60 * NFEATURES,
+    "match.window": MATCH_BYTES_PER_FRAME,
+}
+
+
+def synth_batch(batch, seed, n_distinct=16):
+    import synth_frames as sf
+    sc = sf.Scene(W, H, "desk", seed)
+    base = np.stack([sc.gray(t) for t in range(min(n_distinct, batch))], 0)
+    reps = (batch + len(base) - 1) // len(base)
+    # forward then backward in time so consecutive frames always differ by one drift step
+    seq = np.concatenate([base, base[::-1]], 0)
+    return np.ascontiguousarray(np.concatenate([seq] * reps, 0)[:batch])
+
+
+def cpu_baseline(sample_frames):
+    """Oracle (CPU restatement) timed single-threaded on the same workload: extract + match."""
+    import ctypes as C
+    import oracle_lib
+    odir = os.path.join(ROOT, "oracle")
+    native = os.path.join(odir, "libpsl_oracle_native.so")
+    try:  # -O3 -march=native build for timing, made on this host
+        srcs = sorted(os.path.join(odir, f) for f in os.listdir(odir) if f.endswith(".cpp"))
+        subprocess.run(["g++", "-O3", "-march=native", "-ffp-contract=off", "-std=c++17", "-fPIC", "-shared", "-o", native] + srcs + ["-lm"],
+                       check=True, capture_output=True)
+        oracle_lib.SO = native
+        oracle_lib._lib = None
+    except Exception:
+        pass
+    orc = oracle_lib.OracleORB(NFEATURES, SCALE, NLEVELS, INI_TH, MIN_TH)
+    scale = np.cumprod(np.concatenate([[np.float32(1.0)], np.full(NLEVELS - 1, SCALE, np.float64)])).astype(np.float32)
+    prev = None
+    t0 = time.perf_counter()
+    n = 0
+    for img in sample_frames:
+        kps, desc = orc(img)
+        if prev is not None:
+            q = np.zeros(len(prev[0]), oracle_lib.PROJQUERY_DTYPE)
+            q["u"], q["v"] = prev[0]["x"], prev[0]["y"]
+            q["radius"] = np.float32(15.0) * scale[prev[0]["octave"]]
+            q["min_level"], q["max_level"] = prev[0]["octave"] - 1, prev[0]["octave"] + 1
+            q["angle"], q["blocks"] = prev[0]["angle"], 1
+            oracle_lib.search_by_projection_last(kps, desc, None, (0.0, 0.0, float(W), float(H)), q, prev[1], None, True)
+        prev = (kps, desc)
+        n += 1
+        if time.perf_counter() - t0 > 25.0:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": round(n / dt, 2), "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": f"{n} frames 640x480 desk-like synthetic stream, ORB 1000 extract + SearchByProjection(cur,last), "
+                      f"oracle/ built -O3 -march=native, 1 thread, {dt:.1f} s on {os.cpu_count()} host cores available"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=256, help="frames per step per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE {world}"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import psl_slam_amd as P
+    from importlib import import_module
+    multigpu = import_module("psl_slam_amd.multigpu")
+    P.build()
+    B = args.batch
+    frames_h = synth_batch(B, P_seed(rank))
+    frames_d = torch.from_numpy(frames_h).to(dev)
+
+    # a real (non-null) torch stream: the library launches on it, so torch ops, RCCL and the HIP
+    # kernels are ordered on one stream and torch.cuda events/synchronize see everything
+    stream = torch.cuda.Stream(dev)
+    torch.cuda.set_stream(stream)
+    ctx = P.Context(local_rank, stream.cuda_stream)
+    orb = P.ORBextractor(NFEATURES, SCALE, NLEVELS, INI_TH, MIN_TH, ctx=ctx, max_batch=B)
+    cap = orb.max_keypoints(W, H)
+    grid = P.FrameGrid(cap, B, ctx=ctx)
+    bounds = (0.0, 0.0, float(W), float(H))
+
+    # device-side stand-in for Tracking's constant-velocity projection: the last frame's keypoints
+    # are predicted at the same pixel (drift <= 2 px/frame), window th = 15 * scale[octave]
+    scale_t = torch.tensor(np.cumprod(np.concatenate([[np.float32(1.0)], np.full(NLEVELS - 1, SCALE, np.float64)])).astype(np.float32), device=dev)
+    queries = torch.zeros((B, cap, 8), dtype=torch.float32, device=dev)
+    qdesc = torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev)
+    nq = torch.zeros((B,), dtype=torch.int32, device=dev)
+    match = torch.full((B, cap), -1, dtype=torch.int32, device=dev)
+    nmatches = torch.zeros((B,), dtype=torch.int32, device=dev)
+    q_i32 = queries.view(torch.int32)
+
+    gather = None
+
+    def step():
+        orb.extract_batch_device(frames_d.data_ptr(), B, W, H, W, W * H)
+        k_arr, d_arr, c_arr, _ = P.orb_results_as_arrays(orb, B)
+        kps = torch.as_tensor(k_arr, device=dev)
+        desc = torch.as_tensor(d_arr, device=dev)
+        counts = torch.as_tensor(c_arr, device=dev)
+        grid.set_from_orb(orb, bounds)
+        # queries of pair f = keypoints of frame f-1 (cyclic inside the batch)
+        prev = torch.roll(kps, 1, 0)
+        octv = prev[..., 5].view(torch.int32)
+        queries[..., 0] = prev[..., 0]
+        queries[..., 1] = prev[..., 1]
+        queries[..., 2] = 15.0 * scale_t[octv.clamp(0, NLEVELS - 1).long()]
+        queries[..., 3] = 0.0
+        q_i32[..., 4] = octv - 1
+        q_i32[..., 5] = octv + 1
+        queries[..., 6] = prev[..., 3]
+        q_i32[..., 7] = 1
+        qdesc.copy_(torch.roll(desc, 1, 0))
+        nq.copy_(torch.roll(counts, 1, 0))
+        P.search_by_projection_last_device(grid, 0, B, queries.data_ptr(), qdesc.data_ptr(), nq.data_ptr(), cap, True,
+                                           match.data_ptr(), nmatches.data_ptr())
+        if gather is not None:
+            gather.submit([counts, kps, desc, match, nmatches])
+        return counts
+
+    counts = step()  # first call allocates buffers / builds tables
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        k_arr, d_arr, c_arr, _ = P.orb_results_as_arrays(orb, B)
+        tmpl = [torch.as_tensor(c_arr, device=dev), torch.as_tensor(k_arr, device=dev), torch.as_tensor(d_arr, device=dev), match, nmatches]
+        gather = multigpu.ResultGather(tmpl, world, dev)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize(dev)
+    ctx.profile_reset()
+    ctx.profile(True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        counts = step()
+    if gather is not None:
+        gather.wait()
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ctx.profile(False)
+
+    stage_names = ["orb.pyramid", "orb.fast", "orb.octree", "orb.blur", "orb.describe", "match.grid", "match.window"]
+    stages = {}
+    for s in stage_names:
+        ms, n = ctx.stage_time(s)
+        if n:
+            stages[s] = {"ms_per_launch": ms / n, "launches": n}
+    mean_kp = float(counts.float().mean().item())
+    mean_matches = float(nmatches.float().mean().item())
+
+    if rank == 0:
+        fps = world * B * args.steps / dt
+        dom = max(stages, key=lambda s: stages[s]["ms_per_launch"])
+        dom_bytes = STAGE_BYTES_PER_FRAME[dom] * B
+        dom_s = stages[dom]["ms_per_launch"] * 1e-3
+        achieved = dom_bytes / dom_s / 1e9
+        out = {
+            "metric": "frames/sec ORB extract+match, 640x480", "value": round(fps, 1), "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "configs[1]: 640x480 synthetic RGB-D stream (desk-like), ORB 1000/1.2/8 FAST 20/7 "
+                                   "extract + SearchByProjection(cur,last) match, frames resident in HBM",
+                       "frames_per_step_per_gpu": B, "mean_keypoints": round(mean_kp, 1), "mean_matches": round(mean_matches, 1),
+                       "multi_gpu": "independent stream per rank, RCCL all-gather of result records" if world > 1 else "single GPU"},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "algorithmic_bytes_per_launch": dom_bytes, "ms_per_launch": round(stages[dom]["ms_per_launch"], 4)},
+            "pipeline_roofline": {"bytes_per_frame": ORB_BYTES_PER_FRAME + MATCH_BYTES_PER_FRAME,
+                                  "achieved_GBs": round(fps / world * (ORB_BYTES_PER_FRAME + MATCH_BYTES_PER_FRAME) / 1e9, 2),
+                                  "frac_of_8TBs": round(fps / world * (ORB_BYTES_PER_FRAME + MATCH_BYTES_PER_FRAME) / 1e9 / HBM_PEAK_GBS, 5)},
+            "stages_ms_per_launch": {k: round(v["ms_per_launch"], 4) for k, v in stages.items()},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(frames_h[:64])
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def P_seed(rank):
+    import synth_frames as sf
+    return sf.SEED + 1000 * rank
+
+
+if __name__ == "__main__":
+    main()

@@ -353,3 +353,28 @@ class LSDmatcher:
         return nm.value, m12[:len(d1)]
 
     match = matchNNR  # LSDmatcher::match's live branch is matchNNR (:378-413)
+
+
+class _DevArray:
+    """Zero-copy view of library-owned HBM for frameworks that read __cuda_array_interface__
+    (torch.as_tensor(view, device='cuda') aliases the memory; nothing is copied)."""
+
+    def __init__(self, ptr, shape, typestr):
+        self.__cuda_array_interface__ = {"data": (int(ptr), False), "shape": tuple(shape), "typestr": typestr,
+                                         "version": 2, "strides": None}
+
+
+def orb_results_as_arrays(orb, nframes):
+    """(kps [F,cap,7] f32-view, desc [F,cap,32] u8, counts [F] i32) device views of the last batch."""
+    k, d, c, cap = orb.results_device()
+    return (_DevArray(k, (nframes, cap, 7), "<f4"), _DevArray(d, (nframes, cap, 32), "|u1"),
+            _DevArray(c, (nframes,), "<i4"), cap)
+
+
+def search_by_projection_last_device(frame, slot0, npairs, d_queries, d_qdesc, d_nq, qstride, check_orientation,
+                                     d_match, d_nmatches):
+    """Batched HBM-resident SearchByProjection(cur,last); all d_* are device addresses (ints)."""
+    _check(lib().pslfe_orb_search_by_projection_last_device(
+        frame._h, C.c_int(slot0), C.c_int(npairs), C.c_void_p(d_queries), C.c_void_p(d_qdesc), C.c_void_p(d_nq),
+        C.c_int(qstride), C.c_int(1 if check_orientation else 0), C.c_void_p(d_match), C.c_void_p(d_nmatches)),
+        "pslfe_orb_search_by_projection_last_device")

@@ -178,3 +178,18 @@ def test_hamming_knn2_and_match_nnr():
     ridx, rdist = oracle_lib.hamming_knn2(Q, T)
     np.testing.assert_array_equal(idx, ridx)
     np.testing.assert_array_equal(dist, rdist)
+
+
+def test_hip_reproduces_committed_match_golden():
+    import os
+    import psl_slam_amd as P
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "match_640x480_desk.npz"))
+    grid = P.FrameGrid(2048, 1)
+    grid.set(0, g["k1"], g["d1"], BOUNDS)
+    nm, match, assigned = P.ORBmatcher(0.9, True).SearchByProjectionLast(grid, 0, g["queries"], g["qdesc"])
+    assert nm == int(g["nmatches"])
+    np.testing.assert_array_equal(match, g["match"])
+    np.testing.assert_array_equal(assigned, g["assigned"])
+    idx, dist = P.hamming_knn2(g["qdesc"][:200], g["d1"][:200])
+    np.testing.assert_array_equal(idx, g["knn_idx"])
+    np.testing.assert_array_equal(dist, g["knn_dist"])

@@ -1,0 +1,89 @@
+"""Oracle of the matching functions vs independent numpy restatements and the golden vectors."""
+import os
+
+import numpy as np
+
+import oracle_lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+BOUNDS = (0.0, 0.0, 640.0, 480.0)
+
+
+def popcount_dist(a, b):
+    return int(np.unpackbits(np.bitwise_xor(a, b)).sum())
+
+
+def test_swar_hamming_equals_popcount():
+    rng = np.random.default_rng(0)
+    for _ in range(500):
+        a, b = rng.integers(0, 256, (2, 32), dtype=np.uint8)
+        assert oracle_lib.hamming256(a, b) == popcount_dist(a, b)
+    z = np.zeros(32, np.uint8)
+    assert oracle_lib.hamming256(z, ~z) == 256 and oracle_lib.hamming256(z, z) == 0
+
+
+def test_knn2_ordering_and_ties():
+    rng = np.random.default_rng(1)
+    t = rng.integers(0, 256, (60, 32), dtype=np.uint8)
+    q = rng.integers(0, 256, (40, 32), dtype=np.uint8)
+    t[7] = t[3]
+    q[0] = t[3]
+    idx, dist = oracle_lib.hamming_knn2(q, t)
+    D = np.array([[popcount_dist(a, b) for b in t] for a in q])
+    order = np.argsort(D, axis=1, kind="stable")  # stable: lower train index first on ties
+    np.testing.assert_array_equal(idx, order[:, :2])
+    np.testing.assert_array_equal(dist, np.take_along_axis(D, order[:, :2], 1))
+    assert list(idx[0]) == [3, 7]
+    n, m12 = oracle_lib.line_match_nnr(q, t, 0.9)
+    exp = np.where(dist[:, 0].astype(np.float32) < dist[:, 1].astype(np.float32) * np.float32(0.9), idx[:, 0], -1)
+    np.testing.assert_array_equal(m12, exp)
+    assert n == (exp >= 0).sum()
+
+
+def test_grid_against_bruteforce():
+    g = np.load(os.path.join(GOLD, "match_640x480_desk.npz"))
+    k1 = g["k1"]
+    start, idx = oracle_lib.grid_build(k1, BOUNDS)
+    px = np.floor((k1["x"] - np.float32(0)) * np.float32(64.0 / 640.0) + np.float32(0.5)).astype(int)  # round half away (x >= 0)
+    py = np.floor((k1["y"] - np.float32(0)) * np.float32(48.0 / 480.0) + np.float32(0.5)).astype(int)
+    ok = (px >= 0) & (px < 64) & (py >= 0) & (py < 48)
+    cell = px * 48 + py
+    exp = [i for c in range(64 * 48) for i in np.flatnonzero(ok & (cell == c))]
+    assert list(idx) == exp and start[-1] == len(exp)
+
+
+def test_search_by_projection_golden_and_invariants():
+    g = np.load(os.path.join(GOLD, "match_640x480_desk.npz"))
+    nm, match, assigned = oracle_lib.search_by_projection_last(g["k1"], g["d1"], None, BOUNDS, g["queries"], g["qdesc"], None, True)
+    assert nm == int(g["nmatches"])
+    np.testing.assert_array_equal(match, g["match"])
+    np.testing.assert_array_equal(assigned, g["assigned"])
+    m = match[match >= 0]
+    assert len(np.unique(m)) == len(m)            # every query blocks: a keypoint is given away once
+    for qi in np.flatnonzero(match >= 0)[:200]:   # TH_HIGH gate and window gate
+        c = match[qi]
+        assert popcount_dist(g["qdesc"][qi], g["d1"][c]) <= 100
+        assert abs(g["k1"]["x"][c] - g["queries"]["u"][qi]) < g["queries"]["radius"][qi]
+        assert assigned[c] == qi
+    idx, dist = oracle_lib.hamming_knn2(g["qdesc"][:200], g["d1"][:200])
+    np.testing.assert_array_equal(idx, g["knn_idx"])
+    np.testing.assert_array_equal(dist, g["knn_dist"])
+
+
+def test_search_by_projection_sequential_semantics_small():
+    """Hand-built case: two queries prefer the same keypoint; the later one must fall back to its
+    second choice iff the earlier one blocks (src/ORBmatcher.cc:1401-1403)."""
+    kps = np.zeros(3, oracle_lib.KEYPOINT_DTYPE)
+    kps["x"], kps["y"], kps["octave"] = [100, 104, 300], [100, 100, 300], 0
+    desc = np.zeros((3, 32), np.uint8)
+    desc[1, 0] = 0b00000111                      # keypoint 1 is 3 bits from keypoint 0
+    q = np.zeros(2, oracle_lib.PROJQUERY_DTYPE)
+    q["u"], q["v"], q["radius"], q["min_level"], q["max_level"] = 102, 100, 15, -1, -1
+    qd = np.zeros((2, 32), np.uint8)
+    qd[1, 0] = 0b00000001
+    for blocks, exp in ((1, [0, 1]), (0, [0, 0])):
+        q["blocks"] = blocks
+        nm, match, assigned = oracle_lib.search_by_projection_last(kps, desc, None, BOUNDS, q, qd, None, False)
+        assert list(match) == exp and nm == 2
+        assert assigned[0] == (0 if blocks else 1)

@@ -114,3 +114,37 @@ def test_getters_match_reference_tables():
     s = gpu.GetScaleFactors()
     assert s[0] == 1.0 and abs(s[7] - 1.2 ** 7) < 1e-5
     np.testing.assert_array_equal(gpu.GetInverseScaleFactors(), (np.float32(1.0) / s).astype(np.float32))
+
+
+@pytest.mark.parametrize("name", ["orb_640x480_desk", "orb_640x480_struct", "orb_320x240_desk"])
+def test_hip_reproduces_committed_golden_vectors(name):
+    """HIP path vs the fixtures under tests/golden/ (made by the oracle; make_golden.py)."""
+    import os
+    import psl_slam_amd as P
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", name + ".npz"))
+    nf, nl, ini, mn = [int(v) for v in g["cfg"]]
+    gpu = P.ORBextractor(nf, 1.2, nl, ini, mn)
+    kps, desc = gpu(g["image"])
+    assert kps.tobytes() == g["kps"].tobytes()
+    np.testing.assert_array_equal(desc, g["desc"])
+    assert [len(gpu.debug_candidates(0, l)) for l in range(nl)] == list(g["ncand"])
+
+
+def test_full_size_batch_properties():
+    """BASELINE full size (256 frames of 640x480 per launch): size-independent properties — every
+    copy of a frame inside the batch gives the identical result (no cross-frame leakage), counts stay
+    within quota + overshoot, octaves are sorted, and frame 0 equals the single-frame path."""
+    import psl_slam_amd as P
+    base = sf.stream(8, 640, 480, "desk", seed=21)
+    frames = np.ascontiguousarray(np.concatenate([base] * 32, 0))
+    gpu = P.ORBextractor(1000, 1.2, 8, 20, 7, max_batch=256)
+    res = gpu.extract_batch(frames)
+    single = P.ORBextractor(1000, 1.2, 8, 20, 7)
+    k0, d0 = single(base[0])
+    assert res[0][0].tobytes() == k0.tobytes() and (res[0][1] == d0).all()
+    cap = gpu.max_keypoints(640, 480)
+    for f in range(256):
+        k, d = res[f]
+        kb, db = res[f % 8]
+        assert k.tobytes() == kb.tobytes() and (d == db).all(), f"frame {f} differs from its twin {f % 8}"
+        assert 0 < len(k) <= cap and (np.diff(k["octave"]) >= 0).all()
