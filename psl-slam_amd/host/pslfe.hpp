@@ -1,0 +1,165 @@
+// C++ host-side mirror of the reference's extractor / matcher classes over the C ABI
+// (include/pslfe.h).  Header-only, no OpenCV: keypoints are PslKeyPoint (layout == cv::KeyPoint),
+// descriptors std::vector<uint8_t> (N x 32 row-major == cv::Mat N x 32 CV_8U).  The OpenCV-typed
+// adapter a PSL-SLAM maintainer adds on top is shown in INTEGRATION.md.
+//
+// Names, argument meaning and error behaviour follow the reference:
+//   ORBextractor  include/ORBextractor.h:45-114   (operator(), getters)
+//   ORBmatcher    include/ORBmatcher.h:36-104     (SearchByProjection, DescriptorDistance, TH_*)
+//   LSDmatcher    add_inc/LSDmatcher.h:18-75      (matchNNR / match)
+#ifndef PSLFE_HPP
+#define PSLFE_HPP
+
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/pslfe.h"
+
+namespace pslfe {
+
+struct Error : std::runtime_error {
+    int code;
+    Error(int c, const std::string& what) : std::runtime_error(what + ": " + pslfe_last_error()), code(c) {}
+};
+inline void check(int rc, const char* what) { if (rc != PSLFE_OK) throw Error(rc, what); }
+
+class Context {
+public:
+    explicit Context(int device = 0) { check(pslfe_ctx_create(device, &h_), "pslfe_ctx_create"); }
+    ~Context() { pslfe_ctx_destroy(h_); }
+    Context(const Context&) = delete;
+    Context& operator=(const Context&) = delete;
+    pslfe_ctx* get() const { return h_; }
+    void setStream(void* hipStream) { check(pslfe_ctx_set_stream(h_, hipStream), "pslfe_ctx_set_stream"); }
+    void synchronize() { check(pslfe_ctx_synchronize(h_), "pslfe_ctx_synchronize"); }
+private:
+    pslfe_ctx* h_ = nullptr;
+};
+
+class ORBextractor {
+public:
+    enum { HARRIS_SCORE = 0, FAST_SCORE = 1 };
+
+    ORBextractor(Context& ctx, int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST, int maxBatch = 1)
+        : nlevels_(nlevels) {
+        check(pslfe_orb_create(ctx.get(), nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, maxBatch, &h_), "pslfe_orb_create");
+    }
+    ~ORBextractor() { pslfe_orb_destroy(h_); }
+    ORBextractor(const ORBextractor&) = delete;
+    ORBextractor& operator=(const ORBextractor&) = delete;
+
+    // operator()(image, mask, keypoints, descriptors): mask is ignored, as in the reference;
+    // an empty image leaves the outputs untouched (src/ORBextractor.cc:1046).
+    void operator()(const uint8_t* image, int cols, int rows, int step, std::vector<PslKeyPoint>& keypoints,
+                    std::vector<uint8_t>& descriptors) {
+        if (!image || cols <= 0 || rows <= 0) return;
+        const int cap = pslfe_orb_max_keypoints(h_, cols, rows);
+        if (cap < 0) throw Error(cap, "pslfe_orb_max_keypoints");
+        keypoints.resize(cap);
+        descriptors.resize((size_t)cap * 32);
+        int n = 0;
+        check(pslfe_orb_extract(h_, image, cols, rows, step, keypoints.data(), descriptors.data(), cap, &n), "pslfe_orb_extract");
+        keypoints.resize(n);
+        descriptors.resize((size_t)n * 32);  // n == 0 <=> descriptors.release() (:1064-1065)
+    }
+
+    int GetLevels() const { return pslfe_orb_levels(h_); }
+    float GetScaleFactor() const { return pslfe_orb_scale_factor(h_); }
+    std::vector<float> GetScaleFactors() const { return factors(0); }
+    std::vector<float> GetInverseScaleFactors() const { return factors(1); }
+    std::vector<float> GetScaleSigmaSquares() const { return factors(2); }
+    std::vector<float> GetInverseScaleSigmaSquares() const { return factors(3); }
+    pslfe_orb* get() const { return h_; }
+
+private:
+    std::vector<float> factors(int which) const {
+        std::vector<float> v[4];
+        for (auto& x : v) x.resize(nlevels_);
+        check(pslfe_orb_scale_factors(h_, v[0].data(), v[1].data(), v[2].data(), v[3].data()), "pslfe_orb_scale_factors");
+        return v[which];
+    }
+    pslfe_orb* h_ = nullptr;
+    int nlevels_;
+};
+
+// The part of ORB_SLAM2::Frame the matchers read (mvKeysUn, mDescriptors, mvuRight, mGrid).
+class FrameGrid {
+public:
+    FrameGrid(Context& ctx, int maxKeypoints, int maxFrames = 1) {
+        check(pslfe_frame_create(ctx.get(), maxKeypoints, maxFrames, &h_), "pslfe_frame_create");
+    }
+    ~FrameGrid() { pslfe_frame_destroy(h_); }
+    FrameGrid(const FrameGrid&) = delete;
+    FrameGrid& operator=(const FrameGrid&) = delete;
+    void set(int slot, const std::vector<PslKeyPoint>& keysUn, const std::vector<uint8_t>& descriptors, const float* uRight,
+             float mnMinX, float mnMinY, float mnMaxX, float mnMaxY) {
+        check(pslfe_frame_set(h_, slot, keysUn.data(), descriptors.data(), uRight, (int)keysUn.size(), mnMinX, mnMinY, mnMaxX, mnMaxY),
+              "pslfe_frame_set");
+    }
+    pslfe_frame* get() const { return h_; }
+private:
+    pslfe_frame* h_ = nullptr;
+};
+
+class ORBmatcher {
+public:
+    static const int TH_LOW = 50, TH_HIGH = 100, HISTO_LENGTH = 30;  // src/ORBmatcher.cc:37-39
+    ORBmatcher(float nnratio = 0.6f, bool checkOri = true) : mfNNratio(nnratio), mbCheckOrientation(checkOri) {}
+
+    // SearchByProjection(CurrentFrame, LastFrame, th, bMono), src/ORBmatcher.cc:1328: the caller has
+    // projected LastFrame's map points (queries / qdesc); returns nmatches.
+    int SearchByProjection(FrameGrid& cur, int slot, const std::vector<PslProjQuery>& queries, const std::vector<uint8_t>& qdesc,
+                           const uint8_t* taken, std::vector<int32_t>& match, std::vector<int32_t>* assigned = nullptr) {
+        match.assign(queries.size(), -1);
+        int nm = 0;
+        check(pslfe_orb_search_by_projection_last(cur.get(), slot, queries.data(), qdesc.data(), (int)queries.size(), taken,
+                                                  mbCheckOrientation ? 1 : 0, match.data(), assigned ? assigned->data() : nullptr, &nm),
+              "pslfe_orb_search_by_projection_last");
+        return nm;
+    }
+    // SearchByProjection(F, vpMapPoints, th), src/ORBmatcher.cc:45.
+    int SearchByProjectionMap(FrameGrid& cur, int slot, const std::vector<PslProjQuery>& queries, const std::vector<uint8_t>& qdesc,
+                              const uint8_t* taken, std::vector<int32_t>& match, std::vector<int32_t>* assigned = nullptr) {
+        match.assign(queries.size(), -1);
+        int nm = 0;
+        check(pslfe_orb_search_by_projection_map(cur.get(), slot, queries.data(), qdesc.data(), (int)queries.size(), taken, mfNNratio,
+                                                 match.data(), assigned ? assigned->data() : nullptr, &nm),
+              "pslfe_orb_search_by_projection_map");
+        return nm;
+    }
+    // DescriptorDistance, src/ORBmatcher.cc:1647-1663 (host helper, same SWAR popcount)
+    static int DescriptorDistance(const uint8_t* a, const uint8_t* b) {
+        const uint32_t* pa = reinterpret_cast<const uint32_t*>(a);
+        const uint32_t* pb = reinterpret_cast<const uint32_t*>(b);
+        int dist = 0;
+        for (int i = 0; i < 8; ++i) dist += __builtin_popcount(pa[i] ^ pb[i]);
+        return dist;
+    }
+    float mfNNratio;
+    bool mbCheckOrientation;
+};
+
+class LSDmatcher {
+public:
+    static const int TH_HIGH = 80, TH_LOW = 50;  // add_src/LSDmatcher.cpp:12-14
+    LSDmatcher(Context& ctx, float nnratio = 0.95f, bool checkOri = true) : ctx_(ctx), mfNNratio(nnratio), mbCheckOrientation(checkOri) {}
+    // matchNNR(desc1, desc2, nnr, matches_12), add_src/LSDmatcher.cpp:354-376
+    int matchNNR(const std::vector<uint8_t>& desc1, const std::vector<uint8_t>& desc2, float nnr, std::vector<int>& matches_12) {
+        const int n1 = (int)desc1.size() / 32, n2 = (int)desc2.size() / 32;
+        matches_12.assign(n1, -1);
+        int nm = 0;
+        check(pslfe_line_match_nnr(ctx_.get(), desc1.data(), n1, desc2.data(), n2, nnr, matches_12.data(), &nm), "pslfe_line_match_nnr");
+        return nm;
+    }
+    int match(const std::vector<uint8_t>& d1, const std::vector<uint8_t>& d2, float nnr, std::vector<int>& m12) { return matchNNR(d1, d2, nnr, m12); }
+private:
+    Context& ctx_;
+public:
+    float mfNNratio;
+    bool mbCheckOrientation;
+};
+
+}  // namespace pslfe
+#endif
