@@ -133,6 +133,29 @@ int pslfe_orb_debug_level_image(pslfe_orb* orb, int frame, int level, int blurre
 int pslfe_orb_debug_candidates(pslfe_orb* orb, int frame, int level, int32_t* xys, int cap, int* n);
 int pslfe_orb_debug_level_keypoints(pslfe_orb* orb, int frame, int level, int32_t* xys, int cap, int* n);
 
+/* ---- line extractor ---------------------------------------------------------------------------- */
+typedef struct pslfe_line pslfe_line;  /* == LINEextractor object                                  */
+
+/* == LINEextractor::LINEextractor(numOctaves, scale, nLSDFeature, min_line_length)
+ *    add_src/LineExtractor.cpp:6-25; object created once in Tracking (src/Tracking.cc:127).
+ *    Only numOctaves == 1 is supported: every reference YAML sets LINEextractor.nLevels: 1 and the
+ *    contrib detect() call truncates scale 1.2 to int 1 (add_src/LineExtractor.cpp:336-337). */
+int pslfe_line_create(pslfe_ctx* ctx, int numOctaves, float scale, int nLSDFeature, double min_line_length,
+                      int max_batch, pslfe_line** out);
+void pslfe_line_destroy(pslfe_line* line);
+/* == GetLevels / GetScaleFactor / GetScaleFactors ... add_inc/LineExtractor.h:211-233 */
+int pslfe_line_levels(const pslfe_line* line);
+float pslfe_line_scale_factor(const pslfe_line* line);
+int pslfe_line_scale_factors(const pslfe_line* line, float* scale, float* inv_scale, float* sigma2, float* inv_sigma2);
+
+/* == line_descriptor::LSDDetector::detect(image, keylines, scale=1, numOctaves=1) up to the segment
+ *    list: cv::createLineSegmentDetector() defaults + checkLineExtremes
+ *    (Thirdparty/line_descriptor/src/LSDDetector_custom.cpp:166-205). segments: n x (x1,y1,x2,y2). */
+int pslfe_lsd_detect(pslfe_line* line, const uint8_t* gray, int w, int h, int stride, float* segments, int cap, int* n);
+/* Tap for parity tests: LSD working image (f64), level-line angle in degrees (f32, -1024 = NOTDEF;
+ * the reference's double angle is exactly (double)deg * CV_PI/180) and gradient norm (f64). */
+int pslfe_line_debug_gradient(pslfe_line* line, int frame, int* W, int* H, double* scaled, float* angle_deg, double* modgrad);
+
 /* ---- descriptor matching --------------------------------------------------------------------- */
 /* == cv::BFMatcher(NORM_HAMMING).knnMatch(q, t, k=2) as used by LSDmatcher::matchNNR
  *    add_src/LSDmatcher.cpp:354-376 and FrameBFMatch :492-516.  256-bit descriptors, row-major

@@ -68,6 +68,17 @@ int pso_search_by_projection_map(const PsoKeyPoint* kps, const uint8_t* desc, co
 void pso_hamming_knn2(const uint8_t* q, int nq, const uint8_t* t, int nt, int* idx, int* dist);
 int pso_line_match_nnr(const uint8_t* d1, int n1, const uint8_t* d2, int n2, float nnr, int* matches12);
 
+int pso_lsd_detect(const uint8_t* gray, int w, int h, int stride, float* lines, int cap);
+int pso_lsd_gradient(const uint8_t* gray, int w, int h, int stride, double* scaled, double* angles, double* modgrad, int* W, int* H);
+int pso_merge_lines(const float* src, int n, float ang, float dist, float ep, float* dst, int cap);
+int pso_optimize_and_merge(const float* src, int n, int w, int h, PsoKeyLine* out, int cap);
+int pso_line_iterator_count(int w, int h, float x1, float y1, float x2, float y2);
+int pso_lbd_compute(const uint8_t* gray, int w, int h, int stride, const PsoKeyLine* kls, int n, uint8_t* desc, float* fdesc);
+int pso_lbd_sobel(const uint8_t* gray, int w, int h, int stride, short* dx, short* dy);
+int pso_line_extract(const uint8_t* gray, int w, int h, int stride, int nLSDFeature, PsoKeyLine* kls, uint8_t* desc,
+                     double* lineEq, int cap);
+int pso_lil_pair(const float* L, int rows, float radius, float fanThr, int imgCols, int imgRows, float* fans, int cap);
+
 #ifdef __cplusplus
 }
 #endif

@@ -378,3 +378,57 @@ def search_by_projection_last_device(frame, slot0, npairs, d_queries, d_qdesc, d
         frame._h, C.c_int(slot0), C.c_int(npairs), C.c_void_p(d_queries), C.c_void_p(d_qdesc), C.c_void_p(d_nq),
         C.c_int(qstride), C.c_int(1 if check_orientation else 0), C.c_void_p(d_match), C.c_void_p(d_nmatches)),
         "pslfe_orb_search_by_projection_last_device")
+
+
+class LINEextractor:
+    """== ORB_SLAM2::LINEextractor (add_inc/LineExtractor.h:160-255)."""
+
+    def __init__(self, numOctaves=1, scale=1.2, nLSDFeature=200, min_line_length=0.0, ctx=None, max_batch=1):
+        self.ctx = ctx or default_context()
+        self._h = C.c_void_p()
+        self.numOctaves = numOctaves
+        _check(lib().pslfe_line_create(self.ctx._h, C.c_int(numOctaves), C.c_float(scale), C.c_int(nLSDFeature),
+                                       C.c_double(min_line_length), C.c_int(max_batch), C.byref(self._h)), "pslfe_line_create")
+        lib().pslfe_line_scale_factor.restype = C.c_float
+
+    def GetLevels(self):
+        return lib().pslfe_line_levels(self._h)
+
+    def GetScaleFactor(self):
+        return lib().pslfe_line_scale_factor(self._h)
+
+    def GetScaleFactors(self):
+        a = np.zeros(self.numOctaves, np.float32)
+        _check(lib().pslfe_line_scale_factors(self._h, _ptr(a), None, None, None), "pslfe_line_scale_factors")
+        return a
+
+    def lsd_detect(self, image, cap=8192):
+        """LSDDetector::detect up to the clamped segment list -> (n, 4) float32."""
+        assert image.dtype == np.uint8 and image.ndim == 2
+        h, w = image.shape
+        seg = np.zeros((cap, 4), np.float32)
+        n = C.c_int()
+        _check(lib().pslfe_lsd_detect(self._h, _ptr(image), C.c_int(w), C.c_int(h), C.c_int(image.strides[0]), _ptr(seg),
+                                      C.c_int(cap), C.byref(n)), "pslfe_lsd_detect")
+        return seg[:n.value].copy()
+
+    def debug_gradient(self, frame=0):
+        W, H = C.c_int(), C.c_int()
+        _check(lib().pslfe_line_debug_gradient(self._h, C.c_int(frame), C.byref(W), C.byref(H), None, None, None), "pslfe_line_debug_gradient")
+        scaled = np.zeros((H.value, W.value), np.float64)
+        ang = np.zeros((H.value, W.value), np.float32)
+        mod = np.zeros((H.value, W.value), np.float64)
+        _check(lib().pslfe_line_debug_gradient(self._h, C.c_int(frame), C.byref(W), C.byref(H), _ptr(scaled), _ptr(ang), _ptr(mod)),
+               "pslfe_line_debug_gradient")
+        return scaled, ang, mod
+
+    def close(self):
+        if self._h:
+            lib().pslfe_line_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

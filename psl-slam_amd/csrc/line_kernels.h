@@ -1,0 +1,328 @@
+// HIP kernels of the line front-end (gfx950, wave64). Product code.
+// Reference behaviour reproduced:
+//   cv::createLineSegmentDetector() defaults (OpenCV 3.x lsd.cpp, LSD_REFINE_STD; not in the
+//   reference tree, restated from the published algorithm — SURVEY Appendix A.9) behind the contrib
+//   wrapper Thirdparty/line_descriptor/src/LSDDetector_custom.cpp:166-251
+//   optimizeAndMergeLines_lsd            add_src/uselongline.cpp:24-485
+//   BinaryDescriptor::compute (LBD)      Thirdparty/line_descriptor/src/binary_descriptor_custom.cpp:351-413, 1027-1373
+//   CPartiallyRecoverConnectivity        add_src/PartiallyRecoverConnectivity.cpp:14-247
+// Floating point: every operation whose rounding can reach an output is written with explicit,
+// never-contracted single operations in the order the reference evaluates them.
+#ifndef PSL_LINE_KERNELS_H
+#define PSL_LINE_KERNELS_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/pslfe.h"
+#include "psl_device_math.h"
+
+#define PSL_LSD_NOTDEF (-1024.0f)   // angle map label for "gradient undefined" (stored as f32 degrees)
+#define PSL_PI 3.1415926535897932384626433832795
+#define PSL_DEG2RAD (PSL_PI / 180)
+
+struct LineParams {
+    int w, h, stride_pad;     // input image size
+    int W, H;                 // LSD working image: cvRound(w*0.8) x cvRound(h*0.8)
+    int maxseg;               // capacity of the raw segment list per frame
+    int maxkl;                // capacity of the keyline list per frame (after merging)
+    int nfeatures;            // nLSDFeature (top-N by response)
+    double gk[7];             // Gaussian kernel sigma 0.75 (f64)
+    double rho, prec, p;      // gradient threshold, angle tolerance (rad), p = ANG_TH/180
+    int min_reg_size;
+    int lbdK[5];              // integer Gaussian 5x5 sigma 1 (OpenCV 3.2 8-bit path)
+    float gaussG[63], gaussL[21];
+};
+
+__device__ __forceinline__ int psl_reflect101i(int p, int n) {
+    if (n == 1) return 0;
+    while (p < 0 || p >= n) p = p < 0 ? -p : 2 * n - 2 - p;
+    return p;
+}
+
+// ---------------------------------------------------------------------------------------------
+// LSD step 1: GaussianBlur(CV_64F, 7x7, sigma 0.75, REFLECT_101) + resize(0.8, INTER_LINEAR) on
+// doubles. One thread per scaled pixel recomputes the 2x2 blurred samples it needs (8 rows x 2
+// columns of row sums) in the summation order of OpenCV's RowFilter / SymmColumnFilter.
+// Scale 0.8 -> 1/scale = 1.25 and the bilinear weights {0.125,0.375,0.625,0.875} are exact, so
+// the tables are computed inline exactly as cv::resize computes them.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double psl_lsd_rowsum(const uint8_t* __restrict__ row, int x, int w, const double* gk) {
+    double s = PSL_DMUL(gk[0], (double)row[psl_reflect101i(x - 3, w)]);
+#pragma unroll
+    for (int j = 1; j < 7; ++j) s = PSL_DADD(s, PSL_DMUL(gk[j], (double)row[psl_reflect101i(x - 3 + j, w)]));
+    return s;
+}
+
+__device__ __forceinline__ double psl_lsd_blur_at(const uint8_t* __restrict__ img, int stride, int x, int y, int w, int h, const double* gk) {
+    double rs[7];
+#pragma unroll
+    for (int j = 0; j < 7; ++j) rs[j] = psl_lsd_rowsum(img + (size_t)psl_reflect101i(y - 3 + j, h) * stride, x, w, gk);
+    double s = PSL_DMUL(gk[3], rs[3]);
+#pragma unroll
+    for (int j = 1; j <= 3; ++j) s = PSL_DADD(s, PSL_DMUL(gk[3 + j], PSL_DADD(rs[3 + j], rs[3 - j])));
+    return s;
+}
+
+__global__ __launch_bounds__(256) void k_lsd_scale(LineParams P, const uint8_t* __restrict__ gray, int stride, size_t fstride,
+                                                    double* __restrict__ scaled) {
+    const int frame = blockIdx.z;
+    const int dx = blockIdx.x * 64 + (threadIdx.x & 63), dy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (dx >= P.W || dy >= P.H) return;
+    const uint8_t* img = gray + (size_t)frame * fstride;
+    // cv::resize tables (float offsets, float coefficients; horizontal coefficient cleared at the clamps)
+    const double sc = 1. / 0.8;
+    float fx = (float)((dx + 0.5) * sc - 0.5), fy = (float)((dy + 0.5) * sc - 0.5);
+    int sx = (int)__builtin_floorf(fx), sy = (int)__builtin_floorf(fy);
+    fx -= sx; fy -= sy;
+    if (sx < 0) { fx = 0; sx = 0; }
+    if (sx >= P.w - 1) { fx = 0; sx = P.w - 1; }
+    const double a0 = (double)(1.f - fx), a1 = (double)fx, b0 = (double)(1.f - fy), b1 = (double)fy;
+    int sy0 = sy, sy1 = sy + 1;
+    sy0 = sy0 < 0 ? 0 : (sy0 >= P.h ? P.h - 1 : sy0);
+    sy1 = sy1 < 0 ? 0 : (sy1 >= P.h ? P.h - 1 : sy1);
+    double h0, h1;
+    if (sx + 1 < P.w) {
+        h0 = PSL_DADD(PSL_DMUL(psl_lsd_blur_at(img, stride, sx, sy0, P.w, P.h, P.gk), a0), PSL_DMUL(psl_lsd_blur_at(img, stride, sx + 1, sy0, P.w, P.h, P.gk), a1));
+        h1 = PSL_DADD(PSL_DMUL(psl_lsd_blur_at(img, stride, sx, sy1, P.w, P.h, P.gk), a0), PSL_DMUL(psl_lsd_blur_at(img, stride, sx + 1, sy1, P.w, P.h, P.gk), a1));
+    } else {
+        h0 = psl_lsd_blur_at(img, stride, sx, sy0, P.w, P.h, P.gk);
+        h1 = psl_lsd_blur_at(img, stride, sx, sy1, P.w, P.h, P.gk);
+    }
+    scaled[(size_t)frame * P.W * P.H + (size_t)dy * P.W + dx] = PSL_DADD(PSL_DMUL(h0, b0), PSL_DMUL(h1, b1));
+}
+
+// LSD step 2 (ll_angle): 2x2 gradient, norm (f64, correctly rounded sqrt), level-line angle by the
+// f32 fastAtan2 polynomial.  The angle is stored as f32 degrees (the reference's double is exactly
+// double(deg) * DEG_TO_RADS, recomputed where it is used); NOTDEF = -1024.
+__global__ __launch_bounds__(256) void k_lsd_grad(LineParams P, const double* __restrict__ scaled, float* __restrict__ angdeg,
+                                                   double* __restrict__ modgrad) {
+    const int frame = blockIdx.z;
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= P.W || y >= P.H) return;
+    const size_t o = (size_t)frame * P.W * P.H + (size_t)y * P.W + x;
+    if (x == P.W - 1 || y == P.H - 1) { angdeg[o] = PSL_LSD_NOTDEF; modgrad[o] = 0.0; return; }
+    const double* r0 = scaled + (size_t)frame * P.W * P.H + (size_t)y * P.W;
+    const double* r1 = r0 + P.W;
+    const double DA = PSL_DSUB(r1[x + 1], r0[x]), BC = PSL_DSUB(r0[x + 1], r1[x]);
+    const double gx = PSL_DADD(DA, BC), gy = PSL_DSUB(DA, BC);
+    const double norm = __dsqrt_rn(PSL_DADD(PSL_DMUL(gx, gx), PSL_DMUL(gy, gy)) / 4);
+    modgrad[o] = norm;
+    angdeg[o] = norm <= P.rho ? PSL_LSD_NOTDEF : psl_fast_atan2((float)gx, (float)(-gy));
+}
+
+// ---------------------------------------------------------------------------------------------
+// LSD steps 3-6: seeds in raster order, region growing (8-connected, running mean angle), rectangle
+// by inertia axes, density refinement.  The algorithm is a serial chain through `used` and the
+// running angle; one workgroup (one wave) owns one frame and parallelism comes from the frames of
+// the batch.  This first version runs the chain on lane 0.
+// ---------------------------------------------------------------------------------------------
+struct LsdRect { double x1, y1, x2, y2, width; };
+
+struct LsdFrame {
+    int W, H;
+    const float* ang;      // degrees, NOTDEF = -1024
+    const double* mod;
+    uint8_t* used;
+    uint32_t* reg;         // x | y << 16
+};
+
+__device__ __forceinline__ double psl_lsd_angle(const LsdFrame& F, int addr) { return PSL_DMUL((double)F.ang[addr], PSL_DEG2RAD); }
+
+__device__ __forceinline__ bool psl_lsd_aligned(const LsdFrame& F, int addr, double theta, double prec) {
+    const float ad = F.ang[addr];
+    if (ad == PSL_LSD_NOTDEF) return false;
+    double n_theta = PSL_DSUB(theta, PSL_DMUL((double)ad, PSL_DEG2RAD));
+    if (n_theta < 0) n_theta = -n_theta;
+    if (n_theta > (3 * PSL_PI) / 2) {
+        n_theta = PSL_DSUB(n_theta, 2 * PSL_PI);
+        if (n_theta < 0) n_theta = -n_theta;
+    }
+    return n_theta <= prec;
+}
+
+__device__ int psl_lsd_region_grow(const LsdFrame& F, int sx, int sy, double* reg_angle_out, double prec) {
+    int reg_size = 1;
+    const int addr0 = sx + sy * F.W;
+    F.reg[0] = (uint32_t)sx | ((uint32_t)sy << 16);
+    double reg_angle = psl_lsd_angle(F, addr0);
+    float sumdx = (float)cos(reg_angle), sumdy = (float)sin(reg_angle);
+    F.used[addr0] = 1;
+    for (int i = 0; i < reg_size; ++i) {
+        const uint32_t rp = F.reg[i];
+        const int px = (int)(rp & 0xffff), py = (int)(rp >> 16);
+        const int xx_min = max(px - 1, 0), xx_max = min(px + 1, F.W - 1);
+        const int yy_min = max(py - 1, 0), yy_max = min(py + 1, F.H - 1);
+        for (int yy = yy_min; yy <= yy_max; ++yy) {
+            int c = xx_min + yy * F.W;
+            for (int xx = xx_min; xx <= xx_max; ++xx, ++c) {
+                if (F.used[c] != 1 && psl_lsd_aligned(F, c, reg_angle, prec)) {
+                    F.used[c] = 1;
+                    F.reg[reg_size++] = (uint32_t)xx | ((uint32_t)yy << 16);
+                    float sn, cs;
+                    psl_sincosf((float)psl_lsd_angle(F, c), &sn, &cs);
+                    sumdx = PSL_FADD(sumdx, cs);
+                    sumdy = PSL_FADD(sumdy, sn);
+                    reg_angle = PSL_DMUL((double)psl_fast_atan2(sumdy, sumdx), PSL_DEG2RAD);
+                }
+            }
+        }
+    }
+    *reg_angle_out = reg_angle;
+    return reg_size;
+}
+
+__device__ __forceinline__ double psl_angle_diff_signed(double a, double b) {
+    double diff = PSL_DSUB(a, b);
+    while (diff <= -PSL_PI) diff = PSL_DADD(diff, 2 * PSL_PI);
+    while (diff > PSL_PI) diff = PSL_DSUB(diff, 2 * PSL_PI);
+    return diff;
+}
+
+__device__ __forceinline__ double psl_dist_sq(double x1, double y1, double x2, double y2) {
+    const double dx = PSL_DSUB(x2, x1), dy = PSL_DSUB(y2, y1);
+    return PSL_DADD(PSL_DMUL(dx, dx), PSL_DMUL(dy, dy));
+}
+
+__device__ void psl_lsd_region2rect(const LsdFrame& F, int reg_size, double reg_angle, double prec, LsdRect* rec) {
+    double x = 0, y = 0, sum = 0;
+    for (int i = 0; i < reg_size; ++i) {
+        const uint32_t rp = F.reg[i];
+        const int px = (int)(rp & 0xffff), py = (int)(rp >> 16);
+        const double w = F.mod[px + py * F.W];
+        x = PSL_DADD(x, PSL_DMUL((double)px, w));
+        y = PSL_DADD(y, PSL_DMUL((double)py, w));
+        sum = PSL_DADD(sum, w);
+    }
+    x = x / sum; y = y / sum;
+    // get_theta
+    double Ixx = 0, Iyy = 0, Ixy = 0;
+    for (int i = 0; i < reg_size; ++i) {
+        const uint32_t rp = F.reg[i];
+        const int px = (int)(rp & 0xffff), py = (int)(rp >> 16);
+        const double w = F.mod[px + py * F.W];
+        const double dx = PSL_DSUB((double)px, x), dy = PSL_DSUB((double)py, y);
+        Ixx = PSL_DADD(Ixx, PSL_DMUL(PSL_DMUL(dy, dy), w));
+        Iyy = PSL_DADD(Iyy, PSL_DMUL(PSL_DMUL(dx, dx), w));
+        Ixy = PSL_DSUB(Ixy, PSL_DMUL(PSL_DMUL(dx, dy), w));
+    }
+    const double dI = PSL_DSUB(Ixx, Iyy);
+    const double lambda = PSL_DMUL(0.5, PSL_DSUB(PSL_DADD(Ixx, Iyy), __dsqrt_rn(PSL_DADD(PSL_DMUL(dI, dI), PSL_DMUL(PSL_DMUL(4.0, Ixy), Ixy)))));
+    double theta = (fabs(Ixx) > fabs(Iyy)) ? (double)psl_fast_atan2((float)PSL_DSUB(lambda, Ixx), (float)Ixy)
+                                           : (double)psl_fast_atan2((float)Ixy, (float)PSL_DSUB(lambda, Iyy));
+    theta = PSL_DMUL(theta, PSL_DEG2RAD);
+    if (fabs(psl_angle_diff_signed(theta, reg_angle)) > prec) theta = PSL_DADD(theta, PSL_PI);
+    const double dx = cos(theta), dy = sin(theta);
+    double l_min = 0, l_max = 0, w_min = 0, w_max = 0;
+    for (int i = 0; i < reg_size; ++i) {
+        const uint32_t rp = F.reg[i];
+        const double rdx = PSL_DSUB((double)(int)(rp & 0xffff), x), rdy = PSL_DSUB((double)(int)(rp >> 16), y);
+        const double l = PSL_DADD(PSL_DMUL(rdx, dx), PSL_DMUL(rdy, dy));
+        const double w = PSL_DADD(PSL_DMUL(-rdx, dy), PSL_DMUL(rdy, dx));
+        if (l > l_max) l_max = l; else if (l < l_min) l_min = l;
+        if (w > w_max) w_max = w; else if (w < w_min) w_min = w;
+    }
+    rec->x1 = PSL_DADD(x, PSL_DMUL(l_min, dx)); rec->y1 = PSL_DADD(y, PSL_DMUL(l_min, dy));
+    rec->x2 = PSL_DADD(x, PSL_DMUL(l_max, dx)); rec->y2 = PSL_DADD(y, PSL_DMUL(l_max, dy));
+    rec->width = PSL_DSUB(w_max, w_min);
+    if (rec->width < 1.0) rec->width = 1.0;
+}
+
+__device__ __forceinline__ double psl_lsd_density(int reg_size, const LsdRect& r) {
+    return (double)reg_size / PSL_DMUL(__dsqrt_rn(psl_dist_sq(r.x1, r.y1, r.x2, r.y2)), r.width);
+}
+
+// refine() + reduce_region_radius(); returns the final region size or 0 when the region is rejected
+__device__ int psl_lsd_refine(const LsdFrame& F, int reg_size, double reg_angle, double prec, LsdRect* rec, double density_th) {
+    double density = psl_lsd_density(reg_size, *rec);
+    if (density >= density_th) return reg_size;
+    const uint32_t r0 = F.reg[0];
+    const int x0 = (int)(r0 & 0xffff), y0 = (int)(r0 >> 16);
+    const double xc = (double)x0, yc = (double)y0;
+    const double ang_c = psl_lsd_angle(F, x0 + y0 * F.W);
+    double sum = 0, s_sum = 0;
+    int n = 0;
+    for (int i = 0; i < reg_size; ++i) {
+        const uint32_t rp = F.reg[i];
+        const int px = (int)(rp & 0xffff), py = (int)(rp >> 16);
+        F.used[px + py * F.W] = 0;
+        if (__dsqrt_rn(psl_dist_sq(xc, yc, (double)px, (double)py)) < rec->width) {
+            const double ang_d = psl_angle_diff_signed(psl_lsd_angle(F, px + py * F.W), ang_c);
+            sum = PSL_DADD(sum, ang_d);
+            s_sum = PSL_DADD(s_sum, PSL_DMUL(ang_d, ang_d));
+            ++n;
+        }
+    }
+    const double mean_angle = sum / (double)n;
+    const double tau = PSL_DMUL(2.0, __dsqrt_rn(PSL_DADD(PSL_DSUB(s_sum, PSL_DMUL(PSL_DMUL(2.0, mean_angle), sum)) / (double)n, PSL_DMUL(mean_angle, mean_angle))));
+    reg_size = psl_lsd_region_grow(F, x0, y0, &reg_angle, tau);
+    if (reg_size < 2) return 0;
+    psl_lsd_region2rect(F, reg_size, reg_angle, prec, rec);
+    density = psl_lsd_density(reg_size, *rec);
+    if (density >= density_th) return reg_size;
+    // reduce_region_radius
+    const double d1 = psl_dist_sq(xc, yc, rec->x1, rec->y1), d2 = psl_dist_sq(xc, yc, rec->x2, rec->y2);
+    double radSq = d1 > d2 ? d1 : d2;
+    while (density < density_th) {
+        radSq = PSL_DMUL(radSq, 0.75 * 0.75);
+        for (int i = 0; i < reg_size; ++i) {
+            const uint32_t rp = F.reg[i];
+            const int px = (int)(rp & 0xffff), py = (int)(rp >> 16);
+            if (psl_dist_sq(xc, yc, (double)px, (double)py) > radSq) {
+                F.used[px + py * F.W] = 0;
+                F.reg[i] = F.reg[reg_size - 1];
+                F.reg[reg_size - 1] = rp;
+                --reg_size;
+                --i;
+            }
+        }
+        if (reg_size < 2) return 0;
+        psl_lsd_region2rect(F, reg_size, reg_angle, prec, rec);
+        density = psl_lsd_density(reg_size, *rec);
+    }
+    return reg_size;
+}
+
+__global__ __launch_bounds__(64) void k_lsd_grow(LineParams P, const float* __restrict__ angdeg, const double* __restrict__ modgrad,
+                                                  uint8_t* __restrict__ used, uint32_t* __restrict__ reg, float* __restrict__ seg,
+                                                  int* __restrict__ nseg) {
+    const int frame = blockIdx.x;
+    const size_t npx = (size_t)P.W * P.H;
+    LsdFrame F;
+    F.W = P.W; F.H = P.H;
+    F.ang = angdeg + frame * npx; F.mod = modgrad + frame * npx; F.used = used + frame * npx; F.reg = reg + frame * npx;
+    for (size_t i = threadIdx.x; i < npx; i += 64) F.used[i] = 0;
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    float* out = seg + (size_t)frame * P.maxseg * 4;
+    int count = 0;
+    for (int y = 0; y < P.H - 1; ++y)
+        for (int x = 0; x < P.W - 1; ++x) {
+            const int adx = x + y * P.W;
+            if (F.used[adx] != 0 || F.ang[adx] == PSL_LSD_NOTDEF) continue;
+            double reg_angle;
+            int reg_size = psl_lsd_region_grow(F, x, y, &reg_angle, P.prec);
+            if (reg_size < P.min_reg_size) continue;
+            LsdRect rec;
+            psl_lsd_region2rect(F, reg_size, reg_angle, P.prec, &rec);
+            if (!psl_lsd_refine(F, reg_size, reg_angle, P.prec, &rec, 0.7)) continue;
+            if (count < P.maxseg) {
+                // +0.5 offset, /SCALE, float cast; then the contrib wrapper's checkLineExtremes
+                float e[4] = {(float)(PSL_DADD(rec.x1, 0.5) / 0.8), (float)(PSL_DADD(rec.y1, 0.5) / 0.8),
+                              (float)(PSL_DADD(rec.x2, 0.5) / 0.8), (float)(PSL_DADD(rec.y2, 0.5) / 0.8)};
+                if (e[0] < 0) e[0] = 0;
+                if (e[0] >= P.w) e[0] = (float)P.w - 1.0f;
+                if (e[2] < 0) e[2] = 0;
+                if (e[2] >= P.w) e[2] = (float)P.w - 1.0f;
+                if (e[1] < 0) e[1] = 0;
+                if (e[1] >= P.h) e[1] = (float)P.h - 1.0f;
+                if (e[3] < 0) e[3] = 0;
+                if (e[3] >= P.h) e[3] = (float)P.h - 1.0f;
+                out[4 * count] = e[0]; out[4 * count + 1] = e[1]; out[4 * count + 2] = e[2]; out[4 * count + 3] = e[3];
+            }
+            ++count;
+        }
+    nseg[frame] = count < P.maxseg ? count : P.maxseg;
+}
+
+#endif

@@ -179,3 +179,93 @@ def hamming256(a, b):
     a = np.ascontiguousarray(a, np.uint8)
     b = np.ascontiguousarray(b, np.uint8)
     return L.pso_hamming256(_p(a), _p(b))
+
+
+KEYLINE_DTYPE = np.dtype([("angle", "<f4"), ("class_id", "<i4"), ("octave", "<i4"), ("pt_x", "<f4"), ("pt_y", "<f4"),
+                          ("response", "<f4"), ("size", "<f4"), ("startPointX", "<f4"), ("startPointY", "<f4"),
+                          ("endPointX", "<f4"), ("endPointY", "<f4"), ("sPointInOctaveX", "<f4"),
+                          ("sPointInOctaveY", "<f4"), ("ePointInOctaveX", "<f4"), ("ePointInOctaveY", "<f4"),
+                          ("lineLength", "<f4"), ("numOfPixels", "<i4")])
+
+
+def lsd_detect(img, cap=20000):
+    L = load()
+    img = np.ascontiguousarray(img)
+    h, w = img.shape
+    seg = np.zeros((cap, 4), np.float32)
+    L.pso_lsd_detect.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
+    n = L.pso_lsd_detect(_p(img), w, h, img.strides[0], _p(seg), cap)
+    return seg[:n].copy()
+
+
+def lsd_gradient(img):
+    L = load()
+    img = np.ascontiguousarray(img)
+    h, w = img.shape
+    W, H = int(round(w * 0.8)), int(round(h * 0.8))
+    scaled = np.zeros((H, W)); ang = np.zeros((H, W)); mod = np.zeros((H, W))
+    Wc, Hc = C.c_int(), C.c_int()
+    L.pso_lsd_gradient.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.pso_lsd_gradient(_p(img), w, h, img.strides[0], _p(scaled), _p(ang), _p(mod), C.byref(Wc), C.byref(Hc))
+    assert (Wc.value, Hc.value) == (W, H)
+    return scaled, ang, mod
+
+
+def optimize_and_merge(segs, w, h, cap=4096):
+    L = load()
+    segs = np.ascontiguousarray(segs, np.float32).reshape(-1, 4)
+    out = np.zeros(cap, KEYLINE_DTYPE)
+    L.pso_optimize_and_merge.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
+    n = L.pso_optimize_and_merge(_p(segs), len(segs), w, h, _p(out), cap)
+    return out[:n].copy()
+
+
+def merge_lines(segs, ang, dist, ep, cap=8192):
+    L = load()
+    segs = np.ascontiguousarray(segs, np.float32).reshape(-1, 4)
+    out = np.zeros((cap, 4), np.float32)
+    L.pso_merge_lines.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_int]
+    n = L.pso_merge_lines(_p(segs), len(segs), ang, dist, ep, _p(out), cap)
+    return out[:n].copy()
+
+
+def lbd_compute(img, kls, want_float=False):
+    L = load()
+    img = np.ascontiguousarray(img)
+    kls = np.ascontiguousarray(kls, KEYLINE_DTYPE)
+    h, w = img.shape
+    desc = np.zeros((max(len(kls), 1), 32), np.uint8)
+    fdesc = np.zeros((max(len(kls), 1), 72), np.float32)
+    L.pso_lbd_compute.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    L.pso_lbd_compute(_p(img), w, h, img.strides[0], _p(kls), len(kls), _p(desc), _p(fdesc))
+    return (desc[:len(kls)], fdesc[:len(kls)]) if want_float else desc[:len(kls)]
+
+
+def lbd_sobel(img):
+    L = load()
+    img = np.ascontiguousarray(img)
+    h, w = img.shape
+    dx = np.zeros((h, w), np.int16); dy = np.zeros((h, w), np.int16)
+    L.pso_lbd_sobel.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    L.pso_lbd_sobel(_p(img), w, h, img.strides[0], _p(dx), _p(dy))
+    return dx, dy
+
+
+def line_extract(img, nfeatures=200, cap=4096):
+    L = load()
+    img = np.ascontiguousarray(img)
+    h, w = img.shape
+    kls = np.zeros(cap, KEYLINE_DTYPE); desc = np.zeros((cap, 32), np.uint8); eq = np.zeros((cap, 3))
+    L.pso_line_extract.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    n = L.pso_line_extract(_p(img), w, h, img.strides[0], nfeatures, _p(kls), _p(desc), _p(eq), cap)
+    assert n >= 0
+    return kls[:n].copy(), desc[:n].copy(), eq[:n].copy()
+
+
+def lil_pair(lines, radius, fan_thr, cols, rows, cap=65536):
+    L = load()
+    lines = np.ascontiguousarray(lines, np.float32).reshape(-1, 4)
+    fans = np.zeros((cap, 4), np.float32)
+    L.pso_lil_pair.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_int]
+    n = L.pso_lil_pair(_p(lines), len(lines), radius, fan_thr, cols, rows, _p(fans), cap)
+    return fans[:n].copy()
