@@ -80,6 +80,12 @@ int pslfe_ctx_profile(pslfe_ctx* ctx, int enable);
 int pslfe_ctx_profile_reset(pslfe_ctx* ctx);
 int pslfe_ctx_stage_time(pslfe_ctx* ctx, const char* stage, double* ms_total, int* launches);
 
+/* Plain HBM helpers for callers without their own device allocator (synchronous copies). */
+int pslfe_device_alloc(pslfe_ctx* ctx, size_t bytes, void** d_ptr);
+int pslfe_device_free(pslfe_ctx* ctx, void* d_ptr);
+int pslfe_device_upload(pslfe_ctx* ctx, void* d_dst, const void* src, size_t bytes);
+int pslfe_device_download(pslfe_ctx* ctx, void* dst, const void* d_src, size_t bytes);
+
 /* ---- ORB extractor -------------------------------------------------------------------------- */
 /* == ORBextractor::ORBextractor(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST)
  *    src/ORBextractor.cc:410-470; object created once in Tracking (src/Tracking.cc:120).
@@ -155,6 +161,46 @@ int pslfe_lsd_detect(pslfe_line* line, const uint8_t* gray, int w, int h, int st
 /* Tap for parity tests: LSD working image (f64), level-line angle in degrees (f32, -1024 = NOTDEF;
  * the reference's double angle is exactly (double)deg * CV_PI/180) and gradient norm (f64). */
 int pslfe_line_debug_gradient(pslfe_line* line, int frame, int* W, int* H, double* scaled, float* angle_deg, double* modgrad);
+
+/* == LINEextractor::operator()(image, mask, keylines, descriptors, lineVec2d)
+ *    add_inc/LineExtractor.h:167, add_src/LineExtractor.cpp:325-366; called from Frame::ExtractLSD
+ *    src/Frame.cc:494.  LSD -> optimizeAndMergeLines_lsd -> top nLSDFeature by response -> LBD -> 2-D
+ *    line equations.  desc: n x 32 bytes; lineEq: n x 3 doubles (sp x ep normalised by |xy|).
+ *    gray == NULL or w/h <= 0 -> PSLFE_OK with *n = 0 (:327).  mask is not part of the ABI: the
+ *    reference always passes an empty one (src/Frame.cc:493-494). */
+int pslfe_line_extract(pslfe_line* line, const uint8_t* gray, int w, int h, int stride, PslKeyLine* kls, uint8_t* desc,
+                       double* lineEq, int cap, int* n);
+/* Batched many-frames mode, HBM resident, asynchronous on the context's stream. */
+int pslfe_line_extract_batch_device(pslfe_line* line, const uint8_t* d_gray, int nframes, int w, int h, int stride,
+                                    size_t frame_stride);
+/* Device views: keylines [nframes][cap], descriptors [nframes][cap][32], line equations
+ * [nframes][cap][3] f64, counts [nframes]. */
+int pslfe_line_results_device(pslfe_line* line, const PslKeyLine** d_kls, const uint8_t** d_desc, const double** d_lineEq,
+                              const int32_t** d_counts, int* kl_cap);
+/* Copy one frame of the last batch to the host. *status (may be NULL): 0, or bit 1 = more raw segments
+ * than the merge stage holds, bit 2 = cluster list overflow, bit 4 = more merged lines than cap. */
+int pslfe_line_fetch(pslfe_line* line, int frame, PslKeyLine* kls, uint8_t* desc, double* lineEq, int cap, int* n, int* status);
+
+/* == optimizeAndMergeLines_lsd(keylines, img) add_src/uselongline.cpp:449-485 on a segment list
+ *    (MergeLines 0.05/5/15 -> drop < 30 px -> MergeLines 0.03/3/30 -> drop < 50 px -> KeyLines). */
+int pslfe_line_optimize_and_merge(pslfe_line* line, const float* segments, int nseg, int w, int h, PslKeyLine* kls, int cap, int* n);
+/* == BinaryDescriptor::compute(image, keylines, descriptors) for given keylines
+ *    (Thirdparty/line_descriptor/src/binary_descriptor_custom.cpp:540-688, 1027-1373). fdesc (may be
+ *    NULL): the 72-float LBD vectors before binarisation, n x 72. */
+int pslfe_lbd_compute(pslfe_line* line, const uint8_t* gray, int w, int h, int stride, const PslKeyLine* kls, int nkl,
+                      uint8_t* desc, float* fdesc);
+/* Tap: Sobel dx, dy (s16, w x h) of the LBD pre-processing of the last call. */
+int pslfe_line_debug_sobel(pslfe_line* line, int frame, int16_t* dx, int16_t* dy);
+
+/* == CPartiallyRecoverConnectivity(mLines, radius, fans, img, fanThr)
+ *    add_inc/PartiallyRecoverConnectivity.h:13, add_src/PartiallyRecoverConnectivity.cpp:14-133; called
+ *    from Frame::ExtractLSD src/Frame.cc:505 with radius = 20, fanThr = pi/4.  lines: n x 4
+ *    (x1,y1,x2,y2); fans: k x 4 rows (x, y, i, j) after the keep-last de-duplication. */
+int pslfe_lil_pair(pslfe_line* line, const float* lines, int nlines, float radius, float fanThr, int imgCols, int imgRows,
+                   float* fans, int cap, int* nfans);
+/* The same for every frame of the last extracted batch (mLines = keyline end points), HBM resident. */
+int pslfe_line_pair_batch_device(pslfe_line* line, float radius, float fanThr);
+int pslfe_line_fans_fetch(pslfe_line* line, int frame, float* fans, int cap, int* nfans);
 
 /* ---- descriptor matching --------------------------------------------------------------------- */
 /* == cv::BFMatcher(NORM_HAMMING).knnMatch(q, t, k=2) as used by LSDmatcher::matchNNR

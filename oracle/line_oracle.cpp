@@ -12,7 +12,9 @@
 // leaves behaviour open: OpenCV-3.x LSD with default LSD_REFINE_STD (no NFA step);
 // its seed loop walks the coordinate list by index, i.e. in raster order (the bin-sorted links it
 // builds are never followed); std::sort calls whose ties reach the output are stable with index
-// tie-break (H16); no FMA contraction (H6); empty input -> empty output (H12).
+// tie-break (H16); no FMA contraction (H6); empty input -> empty output (H12); unqualified libm
+// calls on float arguments (cos, sin, tan, atan, atan2) resolve to the float overloads, as they do
+// with libstdc++'s <math.h> wrapper (same rule as src/ORBextractor.cc:113 for the ORB path).
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
@@ -485,7 +487,7 @@ void vec4f_to_keyline(const V4& lines, int w, int h, std::vector<PsoKeyLine>& ou
         kl.endPointX = (float)(l[2] * octaveScale); kl.endPointY = (float)(l[3] * octaveScale);
         kl.sPointInOctaveX = l[0]; kl.sPointInOctaveY = l[1]; kl.ePointInOctaveX = l[2]; kl.ePointInOctaveY = l[3];
         kl.lineLength = (float)std::sqrt(std::pow(l[0] - l[2], 2) + std::pow(l[1] - l[3], 2));
-        kl.angle = (float)std::atan2((kl.endPointY - kl.startPointY), (kl.endPointX - kl.startPointX));
+        kl.angle = atan2f((kl.endPointY - kl.startPointY), (kl.endPointX - kl.startPointX));  // float overload (convention, header)
         kl.class_id = (int)i;
         kl.octave = 0;
         kl.size = (kl.endPointX - kl.startPointX) * (kl.endPointY - kl.startPointY);
@@ -562,7 +564,7 @@ struct Lbd {
         const float midX = (float)(0.5 * (kl.sPointInOctaveX + kl.ePointInOctaveX));
         const float midY = (float)(0.5 * (kl.sPointInOctaveY + kl.ePointInOctaveY));
         float dL[2], dO[2];
-        dL[0] = (float)std::cos(kl.angle); dL[1] = (float)std::sin(kl.angle);  // cos(double(float direction))
+        dL[0] = pso_cosf(kl.angle); dL[1] = pso_sinf(kl.angle);  // cos(float) -> float overload == libm cosf/sinf
         dO[0] = -dL[1]; dO[1] = dL[0];
         float sCorX0 = -dL[0] * halfWidth + dL[1] * halfHeight + midX;
         float sCorY0 = -dL[1] * halfWidth - dL[0] * halfHeight + midY;
@@ -646,7 +648,7 @@ struct Lbd {
 // ================================ pairing ================================
 struct RotRect { float cx, cy, sw, sh, angle; };
 
-float det2f(float a, float b, float c, float d) { return (float)((double)a * d - (double)b * c); }  // cv::determinant 2x2 CV_32F
+double det2(float a, float b, float c, float d) { return (double)a * d - (double)b * c; }  // cv::determinant 2x2 CV_32F returns double
 
 }  // namespace
 
@@ -786,9 +788,9 @@ int pso_lil_pair(const float* L, int rows, float radius, float fanThr, int imgCo
             // intersectionOfLines
             float A1 = pdat[1] - pdat[3], B1 = pdat[2] - pdat[0], C1 = pdat[3] * pdat[0] - pdat[1] * pdat[2];
             float A2 = pdat1[1] - pdat1[3], B2 = pdat1[2] - pdat1[0], C2 = pdat1[3] * pdat1[0] - pdat1[1] * pdat1[2];
-            float D = det2f(A1, B1, A2, B2);
-            float X = (float)((double)det2f(-C1, B1, -C2, B2) / D);
-            float Y = (float)((double)det2f(A1, -C1, A2, -C2) / D);
+            float D = (float)det2(A1, B1, A2, B2);              // float D = determinant(tmat1)
+            float X = (float)(det2(-C1, B1, -C2, B2) / D);      // double / float -> double -> float
+            float Y = (float)(det2(A1, -C1, A2, -C2) / D);
             // isPtInRotatedRect (scalar float arithmetic)
             float fx = dcos * (X - rr.cx) + dsin * (Y - rr.cy);
             float fy = dsin * (X - rr.cx) - dcos * (Y - rr.cy);

@@ -1,5 +1,5 @@
 // One-off pinning tool (test infrastructure): compares the oracle's restated sinf/cosf
-// (oracle/psl_math_oracle.h) with this host's libm sinf/cosf for EVERY float in [0, 2*pi].
+// (oracle/psl_math_oracle.h) with this host's libm sinf/cosf for EVERY float in [-2*pi, 2*pi].
 // Usage: ./sincosf_check [nthreads]
 #include <math.h>
 #include <stdint.h>
@@ -15,10 +15,13 @@ static void* run(void* p) {
     job_t* j = (job_t*)p;
     for (uint32_t u = j->lo; u < j->hi; ++u) {
         float x; memcpy(&x, &u, 4);
-        float s0 = sinf(x), c0 = cosf(x);
-        float s1 = pso_sinf(x), c1 = pso_cosf(x);
-        if (memcmp(&s0, &s1, 4)) { if (!j->bad_s && !j->bad_c) j->first_bad = u; j->bad_s++; }
-        if (memcmp(&c0, &c1, 4)) { if (!j->bad_s && !j->bad_c) j->first_bad = u; j->bad_c++; }
+        for (int sg = 0; sg < 2; ++sg) {  // x and -x: LBD feeds line directions in [-pi, pi]
+            float xx = sg ? -x : x;
+            float s0 = sinf(xx), c0 = cosf(xx);
+            float s1 = pso_sinf(xx), c1 = pso_cosf(xx);
+            if (memcmp(&s0, &s1, 4)) { if (!j->bad_s && !j->bad_c) j->first_bad = u; j->bad_s++; }
+            if (memcmp(&c0, &c1, 4)) { if (!j->bad_s && !j->bad_c) j->first_bad = u; j->bad_c++; }
+        }
     }
     return 0;
 }

@@ -95,6 +95,17 @@ class Context:
         _check(lib().pslfe_ctx_stage_time(self._h, stage.encode(), C.byref(ms), C.byref(n)), "pslfe_ctx_stage_time")
         return ms.value, n.value
 
+    def device_array(self, host_array):
+        """Upload a numpy array into freshly allocated HBM; returns (device address, nbytes)."""
+        a = np.ascontiguousarray(host_array)
+        d = C.c_void_p()
+        _check(lib().pslfe_device_alloc(self._h, C.c_size_t(a.nbytes), C.byref(d)), "pslfe_device_alloc")
+        _check(lib().pslfe_device_upload(self._h, d, _ptr(a), C.c_size_t(a.nbytes)), "pslfe_device_upload")
+        return d.value, a.nbytes
+
+    def device_free(self, d_ptr):
+        _check(lib().pslfe_device_free(self._h, C.c_void_p(d_ptr)), "pslfe_device_free")
+
     def close(self):
         if self._h:
             lib().pslfe_ctx_destroy(self._h)
@@ -432,3 +443,99 @@ class LINEextractor:
             self.close()
         except Exception:
             pass
+
+
+def _line_call(self, image, mask=None):
+    """operator()(image, mask, keylines, descriptors, lineVec2d) -> (keylines, descriptors, lineEq)."""
+    if image is None or image.size == 0:
+        return np.zeros(0, KEYLINE_DTYPE), np.zeros((0, 32), np.uint8), np.zeros((0, 3))
+    assert image.dtype == np.uint8 and image.ndim == 2
+    h, w = image.shape
+    cap = 2048
+    kls = np.zeros(cap, KEYLINE_DTYPE)
+    desc = np.zeros((cap, 32), np.uint8)
+    eq = np.zeros((cap, 3), np.float64)
+    n = C.c_int()
+    _check(lib().pslfe_line_extract(self._h, _ptr(image), C.c_int(w), C.c_int(h), C.c_int(image.strides[0]), _ptr(kls), _ptr(desc),
+                                    _ptr(eq), C.c_int(cap), C.byref(n)), "pslfe_line_extract")
+    return kls[:n.value].copy(), desc[:n.value].copy(), eq[:n.value].copy()
+
+
+def _line_extract_batch_device(self, d_ptr, nframes, w, h, stride, frame_stride):
+    _check(lib().pslfe_line_extract_batch_device(self._h, C.c_void_p(d_ptr), C.c_int(nframes), C.c_int(w), C.c_int(h), C.c_int(stride),
+                                                 C.c_size_t(frame_stride)), "pslfe_line_extract_batch_device")
+
+
+def _line_fetch(self, frame, cap=2048):
+    kls = np.zeros(cap, KEYLINE_DTYPE)
+    desc = np.zeros((cap, 32), np.uint8)
+    eq = np.zeros((cap, 3), np.float64)
+    n, st = C.c_int(), C.c_int()
+    _check(lib().pslfe_line_fetch(self._h, C.c_int(frame), _ptr(kls), _ptr(desc), _ptr(eq), C.c_int(cap), C.byref(n), C.byref(st)),
+           "pslfe_line_fetch")
+    return kls[:n.value].copy(), desc[:n.value].copy(), eq[:n.value].copy(), st.value
+
+
+def _line_results_device(self):
+    k, d, e, c, cap = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_int()
+    _check(lib().pslfe_line_results_device(self._h, C.byref(k), C.byref(d), C.byref(e), C.byref(c), C.byref(cap)), "pslfe_line_results_device")
+    return k.value, d.value, e.value, c.value, cap.value
+
+
+def _line_optimize_and_merge(self, segments, w, h, cap=2048):
+    seg = np.ascontiguousarray(segments, np.float32).reshape(-1, 4)
+    kls = np.zeros(cap, KEYLINE_DTYPE)
+    n = C.c_int()
+    _check(lib().pslfe_line_optimize_and_merge(self._h, _ptr(seg), C.c_int(len(seg)), C.c_int(w), C.c_int(h), _ptr(kls), C.c_int(cap),
+                                               C.byref(n)), "pslfe_line_optimize_and_merge")
+    return kls[:n.value].copy()
+
+
+def _line_lbd(self, image, keylines, want_float=False):
+    kls = np.ascontiguousarray(keylines, KEYLINE_DTYPE)
+    h, w = image.shape
+    desc = np.zeros((max(len(kls), 1), 32), np.uint8)
+    fdesc = np.zeros((max(len(kls), 1), 72), np.float32) if want_float else None
+    _check(lib().pslfe_lbd_compute(self._h, _ptr(image), C.c_int(w), C.c_int(h), C.c_int(image.strides[0]), _ptr(kls), C.c_int(len(kls)),
+                                   _ptr(desc), _ptr(fdesc)), "pslfe_lbd_compute")
+    return (desc[:len(kls)], fdesc[:len(kls)]) if want_float else desc[:len(kls)]
+
+
+def _line_debug_sobel(self, w, h, frame=0):
+    dx = np.zeros((h, w), np.int16)
+    dy = np.zeros((h, w), np.int16)
+    _check(lib().pslfe_line_debug_sobel(self._h, C.c_int(frame), _ptr(dx), _ptr(dy)), "pslfe_line_debug_sobel")
+    return dx, dy
+
+
+def _line_pair(self, lines, radius, fanThr, cols, rows, cap=4096):
+    """CPartiallyRecoverConnectivity(mLines, radius, fans, img, fanThr) -> fans (k, 4)."""
+    L = np.ascontiguousarray(lines, np.float32).reshape(-1, 4)
+    fans = np.zeros((cap, 4), np.float32)
+    k = C.c_int()
+    _check(lib().pslfe_lil_pair(self._h, _ptr(L), C.c_int(len(L)), C.c_float(radius), C.c_float(fanThr), C.c_int(cols), C.c_int(rows),
+                                _ptr(fans), C.c_int(cap), C.byref(k)), "pslfe_lil_pair")
+    return fans[:k.value].copy()
+
+
+def _line_pair_batch_device(self, radius=20.0, fanThr=np.pi / 4):
+    _check(lib().pslfe_line_pair_batch_device(self._h, C.c_float(radius), C.c_float(fanThr)), "pslfe_line_pair_batch_device")
+
+
+def _line_fans_fetch(self, frame, cap=4096):
+    fans = np.zeros((cap, 4), np.float32)
+    k = C.c_int()
+    _check(lib().pslfe_line_fans_fetch(self._h, C.c_int(frame), _ptr(fans), C.c_int(cap), C.byref(k)), "pslfe_line_fans_fetch")
+    return fans[:k.value].copy()
+
+
+LINEextractor.__call__ = _line_call
+LINEextractor.extract_batch_device = _line_extract_batch_device
+LINEextractor.fetch = _line_fetch
+LINEextractor.results_device = _line_results_device
+LINEextractor.optimize_and_merge = _line_optimize_and_merge
+LINEextractor.lbd_compute = _line_lbd
+LINEextractor.debug_sobel = _line_debug_sobel
+LINEextractor.pair = _line_pair
+LINEextractor.pair_batch_device = _line_pair_batch_device
+LINEextractor.fans_fetch = _line_fans_fetch

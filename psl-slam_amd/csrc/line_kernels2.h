@@ -1,0 +1,626 @@
+// HIP kernels of the line front-end, part 2: line merging + KeyLine construction, LBD descriptor,
+// structural-line (LIL/LJL) pairing.  Product code.  See line_kernels.h for the reference map.
+// Convention shared with the oracle: unqualified libm calls on float arguments in the reference
+// (atan, atan2, tan, sin, cos) are the float overloads; sinf/cosf are psl_sincosf (bit-identical to
+// glibc on [-2pi, 2pi]), atanf/atan2f/tanf and the double atan/sin/cos of MergeTwoLines come from the
+// device math library (last-ulp differences vs glibc are possible there; tolerance in the tests).
+#ifndef PSL_LINE_KERNELS2_H
+#define PSL_LINE_KERNELS2_H
+
+#include "line_kernels.h"
+
+#define PSL_MERGE_NMAX 4096    // most segments MergeLines handles per frame
+#define PSL_MERGE_CLMAX 65536  // capacity of the concatenated (sub-)cluster lists
+#define PSL_FAN_CAP 4096       // rows of the fans matrix before de-duplication, per frame
+
+struct MergeScratch {  // base pointers; frame f uses base + f * (per-frame size)
+    float* lines0;     // [NMAX][4]
+    float* lines1;     // [NMAX][4]
+    float* merged;     // [NMAX][4]
+    float* angles;     // [NMAX]
+    float* length;     // [NMAX]
+    int* order;        // sorted position -> index
+    int* pos;          // index -> sorted position
+    uint32_t* adj;     // [NMAX][NMAX/32] over sorted positions
+    int* code;         // [NMAX]
+    int* clist;        // [CLMAX]
+    int* coff;         // [2*NMAX+2]
+    int* work;         // [4*NMAX]
+    uint32_t* bits;    // [NMAX/32]
+    PslKeyLine* stage; // [NMAX]
+};
+
+__device__ __forceinline__ float psl_point_line_distance(const float* l, float x0, float y0) {  // uselongline.cpp:5-15
+    const float x1 = l[0], y1 = l[1], x2 = l[2], y2 = l[3];
+    const float numf = __builtin_fabsf(PSL_FADD(PSL_FADD(PSL_FMUL(PSL_FSUB(y2, y1), x0), PSL_FMUL(PSL_FSUB(x1, x2), y0)),
+                                                PSL_FSUB(PSL_FMUL(x2, y1), PSL_FMUL(x1, y2))));
+    const double a = (double)PSL_FSUB(y2, y1), b = (double)PSL_FSUB(x1, x2);  // std::pow(float, 2) promotes to double
+    const double den = __dsqrt_rn(PSL_DADD(PSL_DMUL(a, a), PSL_DMUL(b, b)));
+    return (float)((double)numf / den);
+}
+
+__device__ __forceinline__ float psl_angle_diff_f(float a1, float a2) {  // :17-22
+    const float c1 = __builtin_fabsf(PSL_FSUB(a2, a1));
+    const float c2 = (float)PSL_DSUB(PSL_DADD(PSL_PI, (double)fminf(a1, a2)), (double)fmaxf(a1, a2));
+    return fminf(c1, c2);
+}
+
+// pair test of MergeLines (:61-156); idx1 is the line at the earlier sorted position
+__device__ bool psl_merge_pair(const float* src, const float* angles, int idx1, int idx2, float angle_thr, float distance_thr, float ep_thr) {
+    float x11 = src[4 * idx1], y11 = src[4 * idx1 + 1], x12 = src[4 * idx1 + 2], y12 = src[4 * idx1 + 3];
+    const float angle1 = angles[idx1];
+    const bool to_sort_x = __builtin_fabsf(angle1) < (float)(PSL_PI / 4.0);
+    if ((to_sort_x && (x12 < x11)) || ((!to_sort_x) && y12 < y11)) { float t = x11; x11 = x12; x12 = t; t = y11; y11 = y12; y12 = t; }
+    float x21 = src[4 * idx2], y21 = src[4 * idx2 + 1], x22 = src[4 * idx2 + 2], y22 = src[4 * idx2 + 3];
+    if ((to_sort_x && (x22 < x21)) || ((!to_sort_x) && y22 < y21)) { float t = x21; x21 = x22; x22 = t; t = y21; y21 = y22; y22 = t; }
+    if (psl_angle_diff_f(angle1, angles[idx2]) > angle_thr) return false;
+    const float mid_x1 = (float)PSL_DMUL(0.5, (double)PSL_FADD(src[4 * idx1], src[4 * idx1 + 2]));
+    const float mid_y1 = (float)PSL_DMUL(0.5, (double)PSL_FADD(src[4 * idx1 + 1], src[4 * idx1 + 3]));
+    const float mid_x2 = (float)PSL_DMUL(0.5, (double)PSL_FADD(src[4 * idx2], src[4 * idx2 + 2]));
+    const float mid_y2 = (float)PSL_DMUL(0.5, (double)PSL_FADD(src[4 * idx2 + 1], src[4 * idx2 + 3]));
+    const float m1 = psl_point_line_distance(&src[4 * idx2], mid_x1, mid_y1);
+    const float m2 = psl_point_line_distance(&src[4 * idx1], mid_x2, mid_y2);
+    if (m1 > distance_thr && m2 > distance_thr) return false;
+    float cx12, cy12, cx21, cy21;
+    if ((to_sort_x && x12 > x22) || (!to_sort_x && y12 > y22)) { cx12 = x22; cy12 = y22; cx21 = x11; cy21 = y11; }
+    else { cx12 = x12; cy12 = y12; cx21 = x21; cy21 = y21; }
+    bool to_merge = ((to_sort_x && cx12 >= cx21) || (!to_sort_x && cy12 >= cy21));
+    if (!to_merge) {
+        const float ex = PSL_FSUB(cx21, cx12), ey = PSL_FSUB(cy21, cy12);
+        to_merge = PSL_FADD(PSL_FMUL(ex, ex), PSL_FMUL(ey, ey)) < ep_thr;
+    }
+    return to_merge;
+}
+
+__device__ void psl_merge_two_lines(const float* l1, const float* l2, float* out) {  // :266-334
+    const float ax = l1[0], ay = l1[1], bx = l1[2], by = l1[3], cx = l2[0], cy = l2[1], dx = l2[2], dy = l2[3];
+    const float dlix = PSL_FSUB(bx, ax), dliy = PSL_FSUB(by, ay), dljx = PSL_FSUB(dx, cx), dljy = PSL_FSUB(dy, cy);
+    const double li = __dsqrt_rn(PSL_DADD((double)PSL_FMUL(dlix, dlix), (double)PSL_FMUL(dliy, dliy)));
+    const double lj = __dsqrt_rn(PSL_DADD((double)PSL_FMUL(dljx, dljx), (double)PSL_FMUL(dljy, dljy)));
+    const double den = PSL_DMUL(2.0, PSL_DADD(li, lj));
+    const double xg = PSL_DADD(PSL_DMUL(li, (double)PSL_FADD(ax, bx)), PSL_DMUL(lj, (double)PSL_FADD(cx, dx))) / den;
+    const double yg = PSL_DADD(PSL_DMUL(li, (double)PSL_FADD(ay, by)), PSL_DMUL(lj, (double)PSL_FADD(cy, dy))) / den;
+    const double thi = dlix == 0.0f ? PSL_PI / 2.0 : (double)atanf(PSL_FDIV(dliy, dlix));
+    const double thj = dljx == 0.0f ? PSL_PI / 2.0 : (double)atanf(PSL_FDIV(dljy, dljx));
+    double thr;
+    if (fabs(PSL_DSUB(thi, thj)) <= PSL_PI / 2.0) thr = PSL_DADD(PSL_DMUL(li, thi), PSL_DMUL(lj, thj)) / PSL_DADD(li, lj);
+    else {
+        const double tmp = PSL_DSUB(thj, PSL_DMUL(PSL_PI, thj / fabs(thj)));
+        thr = PSL_DADD(PSL_DMUL(li, thi), PSL_DMUL(lj, tmp));
+        thr = thr / PSL_DADD(li, lj);
+    }
+    const double s = sin(thr), c = cos(thr);
+    const double axg = PSL_DADD(PSL_DMUL(PSL_DSUB((double)ay, yg), s), PSL_DMUL(PSL_DSUB((double)ax, xg), c));
+    const double bxg = PSL_DADD(PSL_DMUL(PSL_DSUB((double)by, yg), s), PSL_DMUL(PSL_DSUB((double)bx, xg), c));
+    const double cxg = PSL_DADD(PSL_DMUL(PSL_DSUB((double)cy, yg), s), PSL_DMUL(PSL_DSUB((double)cx, xg), c));
+    const double dxg = PSL_DADD(PSL_DMUL(PSL_DSUB((double)dy, yg), s), PSL_DMUL(PSL_DSUB((double)dx, xg), c));
+    const double d1 = fmin(axg, fmin(bxg, fmin(cxg, dxg))), d2 = fmax(axg, fmax(bxg, fmax(cxg, dxg)));
+    out[0] = (float)PSL_DADD(PSL_DMUL(d1, c), xg); out[1] = (float)PSL_DADD(PSL_DMUL(d1, s), yg);
+    out[2] = (float)PSL_DADD(PSL_DMUL(d2, c), xg); out[3] = (float)PSL_DADD(PSL_DMUL(d2, s), yg);
+}
+
+// One MergeLines pass (src[0..n) -> M.merged) followed by FilterShortLines(length_thr) into dst.
+// Called by all 256 threads; returns the new count (uniform).  s_i[1] accumulates the overflow flag.
+__device__ int psl_merge_pass(const MergeScratch& M, const float* src, float* dst, int n, float angle_threshold, float distance_threshold,
+                              float endpoint_threshold, float length_thr, int* s_i) {
+    const int tid = threadIdx.x, BS = 256;
+    if (n <= 0) return 0;
+    const int words = (n + 31) >> 5;
+    const int ROW = PSL_MERGE_NMAX / 32;
+    for (int i = tid; i < n; i += BS) {
+        const float dx = PSL_FSUB(src[4 * i + 2], src[4 * i]), dy = PSL_FSUB(src[4 * i + 3], src[4 * i + 1]);
+        M.angles[i] = atanf(PSL_FDIV(dy, dx));  // Eigen ArrayXf::atan()
+        M.length[i] = sqrtf(PSL_FADD(PSL_FMUL(dx, dx), PSL_FMUL(dy, dy)));
+        M.code[i] = -1;
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += BS) {  // std::sort of indices by angle (stable convention H16): rank by counting
+        const float a = M.angles[i];
+        int r = 0;
+        for (int j = 0; j < n; ++j) { const float b = M.angles[j]; r += (b < a) || (b == a && j < i); }
+        M.pos[i] = r;
+        M.order[r] = i;
+    }
+    __syncthreads();
+    const float ep_thr = PSL_FMUL(endpoint_threshold, endpoint_threshold);
+    for (int t = tid; t < n * words; t += BS) {  // adjacency over sorted positions, one 32-pair word per step
+        const int pi = t / words, wj = t - pi * words;
+        uint32_t bw = 0;
+        const int idxi = M.order[pi];
+        for (int b = 0; b < 32; ++b) {
+            const int pj = wj * 32 + b;
+            if (pj >= n || pj == pi) continue;
+            const int idxj = M.order[pj];
+            const bool m = pi < pj ? psl_merge_pair(src, M.angles, idxi, idxj, angle_threshold, distance_threshold, ep_thr)
+                                   : psl_merge_pair(src, M.angles, idxj, idxi, angle_threshold, distance_threshold, ep_thr);
+            bw |= (uint32_t)m << b;
+        }
+        M.adj[(size_t)pi * ROW + wj] = bw;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        // clustering (:159-188), literally; the std::set<size_t> is a bitset over line indices
+        int ncl = 0, total = 0;
+        int* to_check = M.work;
+        int* next = M.work + PSL_MERGE_NMAX;
+        bool overflow = false;
+        M.coff[0] = 0;
+        for (int i = 0; i < n && !overflow; ++i) {
+            if (M.code[i] >= 0) continue;
+            const int new_code = ncl;
+            M.code[i] = new_code;
+            int ntc = 0;
+            {
+                const uint32_t* row = M.adj + (size_t)M.pos[i] * ROW;
+                for (int w = 0; w < words; ++w) { uint32_t v = row[w]; while (v) { const int b = __ffs(v) - 1; v &= v - 1; to_check[ntc++] = M.order[w * 32 + b]; } }
+            }
+            if (total < PSL_MERGE_CLMAX) M.clist[total++] = i; else overflow = true;
+            while (ntc > 0 && !overflow) {
+                for (int w = 0; w < words; ++w) M.bits[w] = 0;
+                for (int q = 0; q < ntc; ++q) {
+                    const int j = to_check[q];
+                    if (M.code[j] < 0) { M.code[j] = new_code; if (total < PSL_MERGE_CLMAX) M.clist[total++] = j; else overflow = true; }
+                    const uint32_t* row = M.adj + (size_t)M.pos[j] * ROW;
+                    for (int w = 0; w < words; ++w) {
+                        uint32_t v = row[w];
+                        while (v) { const int b = __ffs(v) - 1; v &= v - 1; const int k = M.order[w * 32 + b]; if (M.code[k] < 0) M.bits[k >> 5] |= 1u << (k & 31); }
+                    }
+                }
+                ntc = 0;
+                for (int w = 0; w < words; ++w) { uint32_t v = M.bits[w]; while (v) { const int b = __ffs(v) - 1; v &= v - 1; next[ntc++] = w * 32 + b; } }
+                int* t = to_check; to_check = next; next = t;
+            }
+            M.coff[++ncl] = total;
+        }
+        // sub-clusters (:190-228), appended behind the raw clusters
+        const int raw_ncl = ncl;
+        int* loc = M.work + 2 * PSL_MERGE_NMAX;
+        uint8_t* clustered = reinterpret_cast<uint8_t*>(M.work + 3 * PSL_MERGE_NMAX);
+        int nfinal = 0;
+        int* foff = M.coff + PSL_MERGE_NMAX + 1;
+        foff[0] = total;
+        for (int c = 0; c < raw_ncl && !overflow; ++c) {
+            const int cs = M.coff[c + 1] - M.coff[c];
+            int* cl = M.clist + M.coff[c];
+            if (cs <= 2) {
+                for (int q = 0; q < cs; ++q) { if (total < PSL_MERGE_CLMAX) M.clist[total++] = cl[q]; else overflow = true; }
+                foff[++nfinal] = total;
+                continue;
+            }
+            for (int a = 1; a < cs; ++a) {  // sort by length, descending (stable)
+                const int v = cl[a];
+                const float lv = M.length[v];
+                int b = a - 1;
+                while (b >= 0 && M.length[cl[b]] < lv) { cl[b + 1] = cl[b]; --b; }
+                cl[b + 1] = v;
+            }
+            for (int q = 0; q < cs; ++q) { loc[cl[q]] = q; clustered[q] = 0; }
+            for (int j = 0; j < cs && !overflow; ++j) {
+                if (clustered[j]) continue;
+                const int line_idx = cl[j];
+                if (total < PSL_MERGE_CLMAX) M.clist[total++] = line_idx; else overflow = true;
+                const uint32_t* row = M.adj + (size_t)M.pos[line_idx] * ROW;
+                for (int w = 0; w < words; ++w) {
+                    uint32_t v = row[w];
+                    while (v) {
+                        const int b = __ffs(v) - 1; v &= v - 1;
+                        const int k = M.order[w * 32 + b];
+                        clustered[loc[k]] = 1;
+                        if (total < PSL_MERGE_CLMAX) M.clist[total++] = k; else overflow = true;
+                    }
+                }
+                foff[++nfinal] = total;
+            }
+        }
+        s_i[0] = nfinal;
+        if (overflow) s_i[1] = 1;
+    }
+    __syncthreads();
+    const int nfinal = s_i[0];
+    const int* foff = M.coff + PSL_MERGE_NMAX + 1;
+    for (int c = tid; c < nfinal; c += BS) {  // merge chains (:230-262); the first line is merged with itself first
+        const int* cl = M.clist + foff[c];
+        const int cs = foff[c + 1] - foff[c];
+        float nl[4] = {src[4 * cl[0]], src[4 * cl[0] + 1], src[4 * cl[0] + 2], src[4 * cl[0] + 3]};
+        for (int q = 0; q < cs; ++q) {
+            float o[4];
+            psl_merge_two_lines(nl, &src[4 * cl[q]], o);
+            nl[0] = o[0]; nl[1] = o[1]; nl[2] = o[2]; nl[3] = o[3];
+        }
+        M.merged[4 * c] = nl[0]; M.merged[4 * c + 1] = nl[1]; M.merged[4 * c + 2] = nl[2]; M.merged[4 * c + 3] = nl[3];
+    }
+    __syncthreads();
+    if (tid == 0) {  // FilterShortLines (:338-351), order preserving
+        const float thr2 = PSL_FMUL(length_thr, length_thr);
+        int keep = 0;
+        for (int c = 0; c < nfinal; ++c) {
+            const float* m = M.merged + 4 * c;
+            const float dx = PSL_FSUB(m[2], m[0]), dy = PSL_FSUB(m[3], m[1]);
+            if (PSL_FADD(PSL_FMUL(dx, dx), PSL_FMUL(dy, dy)) > thr2) {
+                dst[4 * keep] = m[0]; dst[4 * keep + 1] = m[1]; dst[4 * keep + 2] = m[2]; dst[4 * keep + 3] = m[3];
+                ++keep;
+            }
+        }
+        s_i[0] = keep;
+    }
+    __syncthreads();
+    const int out_n = s_i[0];
+    __syncthreads();
+    return out_n;
+}
+
+// cv::clipLine (64-bit integer arithmetic) + LineIterator(8-connected).count (Appendix A.8)
+__device__ int psl_line_iterator_count(int w, int h, float fx1, float fy1, float fx2, float fy2) {
+    long long x1 = psl_cvround_f(fx1), y1 = psl_cvround_f(fy1), x2 = psl_cvround_f(fx2), y2 = psl_cvround_f(fy2);
+    if ((unsigned long long)x1 >= (unsigned long long)w || (unsigned long long)x2 >= (unsigned long long)w ||
+        (unsigned long long)y1 >= (unsigned long long)h || (unsigned long long)y2 >= (unsigned long long)h) {
+        const long long right = w - 1, bottom = h - 1;
+        int c1 = (x1 < 0) + (x1 > right) * 2 + (y1 < 0) * 4 + (y1 > bottom) * 8;
+        int c2 = (x2 < 0) + (x2 > right) * 2 + (y2 < 0) * 4 + (y2 > bottom) * 8;
+        if ((c1 & c2) == 0 && (c1 | c2) != 0) {
+            long long a;
+            if (c1 & 12) { a = c1 < 8 ? 0 : bottom; x1 += (a - y1) * (x2 - x1) / (y2 - y1); y1 = a; c1 = (x1 < 0) + (x1 > right) * 2; }
+            if (c2 & 12) { a = c2 < 8 ? 0 : bottom; x2 += (a - y2) * (x2 - x1) / (y2 - y1); y2 = a; c2 = (x2 < 0) + (x2 > right) * 2; }
+            if ((c1 & c2) == 0 && (c1 | c2) != 0) {
+                if (c1) { a = c1 == 1 ? 0 : right; y1 += (a - x1) * (y2 - y1) / (x2 - x1); x1 = a; c1 = 0; }
+                if (c2) { a = c2 == 1 ? 0 : right; y2 += (a - x2) * (y2 - y1) / (x2 - x1); x2 = a; c2 = 0; }
+            }
+        }
+        if ((c1 | c2) != 0) return 0;
+    }
+    long long dx = x2 - x1, dy = y2 - y1;
+    dx = dx < 0 ? -dx : dx; dy = dy < 0 ? -dy : dy;
+    return (int)(dx > dy ? dx : dy) + 1;
+}
+
+// optimizeAndMergeLines_lsd + top-N + line equations: one workgroup per frame.
+// status bits: 1 = more than NMAX raw segments (truncated), 2 = cluster list overflow, 4 = more
+// than maxkl merged lines (truncated).
+__global__ __launch_bounds__(256) void k_line_merge(LineParams P, MergeScratch M0, const float* __restrict__ seg, const int* __restrict__ nseg,
+                                                     PslKeyLine* __restrict__ kls, double* __restrict__ lineEq, int* __restrict__ nkl,
+                                                     int* __restrict__ status) {
+    __shared__ int s_i[4];
+    const int frame = blockIdx.x, tid = threadIdx.x;
+    const size_t f = (size_t)frame;
+    MergeScratch M;
+    M.lines0 = M0.lines0 + f * PSL_MERGE_NMAX * 4; M.lines1 = M0.lines1 + f * PSL_MERGE_NMAX * 4;
+    M.merged = M0.merged + f * PSL_MERGE_NMAX * 4;
+    M.angles = M0.angles + f * PSL_MERGE_NMAX; M.length = M0.length + f * PSL_MERGE_NMAX;
+    M.order = M0.order + f * PSL_MERGE_NMAX; M.pos = M0.pos + f * PSL_MERGE_NMAX;
+    M.adj = M0.adj + f * (size_t)PSL_MERGE_NMAX * (PSL_MERGE_NMAX / 32);
+    M.code = M0.code + f * PSL_MERGE_NMAX; M.clist = M0.clist + f * PSL_MERGE_CLMAX;
+    M.coff = M0.coff + f * (2 * PSL_MERGE_NMAX + 2); M.work = M0.work + f * 4 * PSL_MERGE_NMAX;
+    M.bits = M0.bits + f * (PSL_MERGE_NMAX / 32); M.stage = M0.stage + f * PSL_MERGE_NMAX;
+    if (tid == 0) s_i[1] = 0;
+    int n = nseg[frame];
+    int st = 0;
+    if (n > PSL_MERGE_NMAX) { n = PSL_MERGE_NMAX; st |= 1; }
+    const float* src = seg + f * P.maxseg * 4;
+    for (int i = tid; i < n * 4; i += 256) M.lines0[i] = src[i];
+    __syncthreads();
+    n = psl_merge_pass(M, M.lines0, M.lines1, n, 0.05f, 5.f, 15.f, 30.f, s_i);
+    n = psl_merge_pass(M, M.lines1, M.lines0, n, 0.03f, 3.f, 30.f, 50.f, s_i);
+    st |= s_i[1] << 1;
+    // convertVec4fToKeyLine (:411-447)
+    const float* L = M.lines0;
+    PslKeyLine* out = kls + f * P.maxkl;
+    float* resp = M.angles;
+    for (int i = tid; i < n; i += 256) {
+        const float* l = L + 4 * i;
+        PslKeyLine kl;
+        kl.startPointX = l[0]; kl.startPointY = l[1]; kl.endPointX = l[2]; kl.endPointY = l[3];  // * octaveScale (1.0): exact
+        kl.sPointInOctaveX = l[0]; kl.sPointInOctaveY = l[1]; kl.ePointInOctaveX = l[2]; kl.ePointInOctaveY = l[3];
+        const double ex = (double)PSL_FSUB(l[0], l[2]), ey = (double)PSL_FSUB(l[1], l[3]);
+        kl.lineLength = (float)__dsqrt_rn(PSL_DADD(PSL_DMUL(ex, ex), PSL_DMUL(ey, ey)));
+        kl.angle = atan2f(PSL_FSUB(kl.endPointY, kl.startPointY), PSL_FSUB(kl.endPointX, kl.startPointX));
+        kl.class_id = i;
+        kl.octave = 0;
+        kl.size = PSL_FMUL(PSL_FSUB(kl.endPointX, kl.startPointX), PSL_FSUB(kl.endPointY, kl.startPointY));
+        kl.pt_x = PSL_FADD(kl.endPointX, kl.startPointX) / 2;
+        kl.pt_y = PSL_FADD(kl.endPointY, kl.startPointY) / 2;
+        kl.response = PSL_FDIV(kl.lineLength, (float)(P.w > P.h ? P.w : P.h));
+        kl.numOfPixels = psl_line_iterator_count(P.w, P.h, l[0], l[1], l[2], l[3]);
+        resp[i] = kl.response;
+        M.stage[i] = kl;
+    }
+    __syncthreads();
+    int m = n;
+    if (n > P.nfeatures) {  // sort by response, descending (stable), keep nLSDFeature, class_id = rank (LineExtractor.cpp:342-348)
+        m = P.nfeatures;
+        for (int i = tid; i < n; i += 256) {
+            const float r = resp[i];
+            int rank = 0;
+            for (int j = 0; j < n; ++j) { const float q = resp[j]; rank += (q > r) || (q == r && j < i); }
+            if (rank < m) { PslKeyLine kl = M.stage[i]; kl.class_id = rank; out[rank] = kl; }
+        }
+    } else {
+        if (m > P.maxkl) { m = P.maxkl; st |= 4; }
+        for (int i = tid; i < m; i += 256) out[i] = M.stage[i];
+    }
+    __syncthreads();
+    double* eq = lineEq + f * P.maxkl * 3;
+    for (int i = tid; i < m; i += 256) {  // lineV = sp x ep / |lineV.xy| (LineExtractor.cpp:352-363), double
+        const double sx = out[i].startPointX, sy = out[i].startPointY, ex = out[i].endPointX, ey = out[i].endPointY;
+        const double lx = PSL_DSUB(sy, ey), ly = PSL_DSUB(ex, sx), lz = PSL_DSUB(PSL_DMUL(sx, ey), PSL_DMUL(sy, ex));
+        const double nrm = __dsqrt_rn(PSL_DADD(PSL_DMUL(lx, lx), PSL_DMUL(ly, ly)));
+        eq[3 * i] = lx / nrm; eq[3 * i + 1] = ly / nrm; eq[3 * i + 2] = lz / nrm;
+    }
+    if (tid == 0) { nkl[frame] = m; status[frame] = st; }
+}
+
+// ---------------------------------------------------------------------------------------------
+// LBD pre-processing (binary_descriptor_custom.cpp:351-399): GaussianBlur 5x5 sigma 1 on 8U (integer
+// kernel, sum 257) then Sobel 3x3 -> s16 dx, dy, both BORDER_REFLECT_101.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_lbd_blur5(LineParams P, const uint8_t* __restrict__ gray, int stride, size_t fstride,
+                                                    uint8_t* __restrict__ blur) {
+    const int frame = blockIdx.z;
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= P.w || y >= P.h) return;
+    const uint8_t* img = gray + (size_t)frame * fstride;
+    int col[5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        const uint8_t* row = img + (size_t)psl_reflect101i(y + j - 2, P.h) * stride;
+        int s = 0;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) s += P.lbdK[k] * row[psl_reflect101i(x + k - 2, P.w)];
+        col[j] = s;
+    }
+    int s = 0;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) s += P.lbdK[j] * col[j];
+    int v = (s + (1 << 15)) >> 16;
+    blur[(size_t)frame * P.w * P.h + (size_t)y * P.w + x] = (uint8_t)(v > 255 ? 255 : v);
+}
+
+__global__ __launch_bounds__(256) void k_lbd_sobel(LineParams P, const uint8_t* __restrict__ blur, short* __restrict__ dxo, short* __restrict__ dyo) {
+    const int frame = blockIdx.z;
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= P.w || y >= P.h) return;
+    const uint8_t* b = blur + (size_t)frame * P.w * P.h;
+    const int xm = psl_reflect101i(x - 1, P.w), xp = psl_reflect101i(x + 1, P.w);
+    const int ym = psl_reflect101i(y - 1, P.h), yp = psl_reflect101i(y + 1, P.h);
+    const int a00 = b[(size_t)ym * P.w + xm], a01 = b[(size_t)ym * P.w + x], a02 = b[(size_t)ym * P.w + xp];
+    const int a10 = b[(size_t)y * P.w + xm], a12 = b[(size_t)y * P.w + xp];
+    const int a20 = b[(size_t)yp * P.w + xm], a21 = b[(size_t)yp * P.w + x], a22 = b[(size_t)yp * P.w + xp];
+    const size_t o = (size_t)frame * P.w * P.h + (size_t)y * P.w + x;
+    dxo[o] = (short)((a02 + 2 * a12 + a22) - (a00 + 2 * a10 + a20));
+    dyo[o] = (short)((a20 + 2 * a21 + a22) - (a00 + 2 * a01 + a02));
+}
+
+// ---------------------------------------------------------------------------------------------
+// LBD (computeLBD :1027-1373): one wave per line, lane = row hID of the 63-row line support region.
+// Every float accumulation runs in the reference's order: a lane walks its row left to right, band
+// sums are taken over hID ascending by lanes 0..8, the 72-float normalisation by lane 0.
+// ---------------------------------------------------------------------------------------------
+__constant__ int c_lbd_combos[32][2] = {{0, 1}, {0, 2}, {0, 3}, {0, 4}, {0, 5}, {0, 6}, {1, 2}, {1, 3}, {1, 4}, {1, 5}, {1, 6},
+                                        {2, 3}, {2, 4}, {2, 5}, {2, 6}, {2, 7}, {2, 8}, {3, 4}, {3, 5}, {3, 6}, {3, 7}, {3, 8},
+                                        {4, 5}, {4, 6}, {4, 7}, {4, 8}, {5, 6}, {5, 7}, {5, 8}, {6, 7}, {6, 8}, {7, 8}};
+
+__global__ __launch_bounds__(256) void k_lbd(LineParams P, const short* __restrict__ dxI, const short* __restrict__ dyI,
+                                              const PslKeyLine* __restrict__ kls, const int* __restrict__ nkl, uint8_t* __restrict__ desc,
+                                              float* __restrict__ fdesc) {
+    __shared__ float s_row[4][63][8];
+    __shared__ float s_des[4][72];
+    const int frame = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int line = blockIdx.x * 4 + wave;
+    const bool active = line < nkl[frame];
+    const PslKeyLine kl = kls[(size_t)frame * P.maxkl + (active ? line : 0)];
+    const short* pdx = dxI + (size_t)frame * P.w * P.h;
+    const short* pdy = dyI + (size_t)frame * P.w * P.h;
+    const int NB = 9, WB = 7;
+    const short realWidth = (short)P.w, imageWidth = (short)(realWidth - 1), imageHeight = (short)(P.h - 1);
+    const short lengthOfLSP = (short)kl.numOfPixels;
+    const short halfHeight = (short)((WB * NB - 1) / 2), halfWidth = (short)((lengthOfLSP - 1) / 2);
+    const float midX = (float)PSL_DMUL(0.5, (double)PSL_FADD(kl.sPointInOctaveX, kl.ePointInOctaveX));
+    const float midY = (float)PSL_DMUL(0.5, (double)PSL_FADD(kl.sPointInOctaveY, kl.ePointInOctaveY));
+    float dL0, dL1;
+    psl_sincosf(kl.angle, &dL1, &dL0);  // dL = (cos(direction), sin(direction)), float overloads
+    const float dO0 = -dL1, dO1 = dL0;
+    if (active && lane < 63) {
+        float sCorX0 = PSL_FADD(PSL_FADD(PSL_FMUL(-dL0, (float)halfWidth), PSL_FMUL(dL1, (float)halfHeight)), midX);
+        float sCorY0 = PSL_FADD(PSL_FSUB(PSL_FMUL(-dL1, (float)halfWidth), PSL_FMUL(dL0, (float)halfHeight)), midY);
+        for (int hh = 0; hh < lane; ++hh) { sCorX0 = PSL_FSUB(sCorX0, dL1); sCorY0 = PSL_FADD(sCorY0, dL0); }
+        float sCorX = sCorX0, sCorY = sCorY0;
+        float pL = 0, nL = 0, pO = 0, nO = 0;
+        for (short wID = 0; wID < lengthOfLSP; wID++) {
+            short t = (short)__builtin_roundf(sCorX);
+            const short xCor = (t < 0) ? 0 : (t > imageWidth) ? imageWidth : t;
+            t = (short)__builtin_roundf(sCorY);
+            const short yCor = (t < 0) ? 0 : (t > imageHeight) ? imageHeight : t;
+            const float gx = (float)pdx[(int)yCor * realWidth + xCor], gy = (float)pdy[(int)yCor * realWidth + xCor];
+            const float gDL = PSL_FADD(PSL_FMUL(gx, dL0), PSL_FMUL(gy, dL1));
+            const float gDO = PSL_FADD(PSL_FMUL(gx, dO0), PSL_FMUL(gy, dO1));
+            if (gDL > 0) pL = PSL_FADD(pL, gDL); else nL = PSL_FSUB(nL, gDL);
+            if (gDO > 0) pO = PSL_FADD(pO, gDO); else nO = PSL_FSUB(nO, gDO);
+            sCorX = PSL_FADD(sCorX, dL0);
+            sCorY = PSL_FADD(sCorY, dL1);
+        }
+        const float coef = P.gaussG[lane];
+        pL = PSL_FMUL(coef, pL); nL = PSL_FMUL(coef, nL); pO = PSL_FMUL(coef, pO); nO = PSL_FMUL(coef, nO);
+        float* r = s_row[wave][lane];
+        r[0] = pL; r[1] = nL; r[2] = PSL_FMUL(pL, pL); r[3] = PSL_FMUL(nL, nL);
+        r[4] = pO; r[5] = nO; r[6] = PSL_FMUL(pO, pO); r[7] = PSL_FMUL(nO, nO);
+    }
+    __syncthreads();
+    if (active && lane < NB) {
+        const int b = lane;
+        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // pL, nL, pL2, nL2, pO, nO, pO2, nO2
+        const int h0 = max(0, WB * (b - 1)), h1 = min(WB * NB, WB * (b + 2));
+        for (int hID = h0; hID < h1; ++hID) {
+            const int own = hID / WB;
+            const float c = own == b ? P.gaussL[hID % WB + WB] : (own == b + 1 ? P.gaussL[hID % WB + 2 * WB] : P.gaussL[hID % WB]);
+            const float* r = s_row[wave][hID];
+            const float cc = PSL_FMUL(c, c);
+            acc[0] = PSL_FADD(acc[0], PSL_FMUL(c, r[0])); acc[1] = PSL_FADD(acc[1], PSL_FMUL(c, r[1]));
+            acc[2] = PSL_FADD(acc[2], PSL_FMUL(cc, r[2])); acc[3] = PSL_FADD(acc[3], PSL_FMUL(cc, r[3]));
+            acc[4] = PSL_FADD(acc[4], PSL_FMUL(c, r[4])); acc[5] = PSL_FADD(acc[5], PSL_FMUL(c, r[5]));
+            acc[6] = PSL_FADD(acc[6], PSL_FMUL(cc, r[6])); acc[7] = PSL_FADD(acc[7], PSL_FMUL(cc, r[7]));
+        }
+        const float invN = (b == 0 || b == NB - 1) ? (float)(1.0 / (WB * 2.0)) : (float)(1.0 / (WB * 3.0));
+        float* d = &s_des[wave][8 * b];
+        float temp = PSL_FMUL(acc[0], invN);
+        d[0] = temp; d[4] = sqrtf(PSL_FSUB(PSL_FMUL(acc[2], invN), PSL_FMUL(temp, temp)));
+        temp = PSL_FMUL(acc[1], invN);
+        d[1] = temp; d[5] = sqrtf(PSL_FSUB(PSL_FMUL(acc[3], invN), PSL_FMUL(temp, temp)));
+        temp = PSL_FMUL(acc[4], invN);
+        d[2] = temp; d[6] = sqrtf(PSL_FSUB(PSL_FMUL(acc[6], invN), PSL_FMUL(temp, temp)));
+        temp = PSL_FMUL(acc[5], invN);
+        d[3] = temp; d[7] = sqrtf(PSL_FSUB(PSL_FMUL(acc[7], invN), PSL_FMUL(temp, temp)));
+    }
+    __syncthreads();
+    if (active && lane == 0) {
+        float* v = s_des[wave];
+        float tempM = 0, tempS = 0;
+        for (int b = 0; b < NB; ++b) {
+            const float* q = v + 8 * b;
+            tempM = PSL_FADD(tempM, PSL_FMUL(q[0], q[0])); tempM = PSL_FADD(tempM, PSL_FMUL(q[1], q[1]));
+            tempM = PSL_FADD(tempM, PSL_FMUL(q[2], q[2])); tempM = PSL_FADD(tempM, PSL_FMUL(q[3], q[3]));
+            tempS = PSL_FADD(tempS, PSL_FMUL(q[4], q[4])); tempS = PSL_FADD(tempS, PSL_FMUL(q[5], q[5]));
+            tempS = PSL_FADD(tempS, PSL_FMUL(q[6], q[6])); tempS = PSL_FADD(tempS, PSL_FMUL(q[7], q[7]));
+        }
+        tempM = PSL_FDIV(1.0f, sqrtf(tempM));
+        tempS = PSL_FDIV(1.0f, sqrtf(tempS));
+        for (int b = 0; b < NB; ++b) {
+            float* q = v + 8 * b;
+            q[0] = PSL_FMUL(q[0], tempM); q[1] = PSL_FMUL(q[1], tempM); q[2] = PSL_FMUL(q[2], tempM); q[3] = PSL_FMUL(q[3], tempM);
+            q[4] = PSL_FMUL(q[4], tempS); q[5] = PSL_FMUL(q[5], tempS); q[6] = PSL_FMUL(q[6], tempS); q[7] = PSL_FMUL(q[7], tempS);
+        }
+        for (int i = 0; i < 72; ++i) if ((double)v[i] > 0.4) v[i] = (float)0.4;
+        float temp = 0;
+        for (int i = 0; i < 72; ++i) temp = PSL_FADD(temp, PSL_FMUL(v[i], v[i]));
+        temp = PSL_FDIV(1.0f, sqrtf(temp));
+        for (int i = 0; i < 72; ++i) v[i] = PSL_FMUL(v[i], temp);
+    }
+    __syncthreads();
+    if (!active) return;
+    const size_t o = (size_t)frame * P.maxkl + line;
+    if (lane < 32) {  // binaryConversion (:402-413)
+        const float* f1 = &s_des[wave][8 * c_lbd_combos[lane][0]];
+        const float* f2 = &s_des[wave][8 * c_lbd_combos[lane][1]];
+        uint32_t r = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) r |= (uint32_t)(f1[i] > f2[i]) << i;
+        desc[o * 32 + lane] = (uint8_t)r;
+    }
+    if (fdesc) for (int i = lane; i < 72; i += 64) fdesc[o * 72 + i] = s_des[wave][i];
+}
+
+// ---------------------------------------------------------------------------------------------
+// CPartiallyRecoverConnectivity (PartiallyRecoverConnectivity.cpp:14-133): one workgroup per frame.
+// Rows are produced in the reference's order (line i outer; candidate points = all start points
+// then all end points) by ordered compaction; then the unordered-pair de-duplication that keeps the
+// LAST occurrence.  ptsDropInRotatedRect is evaluated as cv::addWeighted evaluates the folded
+// MatExpr: x*dcos + y*dsin + (float)(-cx*dcos - cy*dsin).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double psl_det2(float a, float b, float c, float d) {  // cv::determinant, 2x2 CV_32F -> double
+    return PSL_DSUB(PSL_DMUL((double)a, (double)d), PSL_DMUL((double)b, (double)c));
+}
+
+__device__ __forceinline__ int psl_block_excl_scan256(int v, int* s_w, int* total) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(inc, o); if (lane >= o) inc += u; }
+    if (lane == 63) s_w[w] = inc;
+    __syncthreads();
+    const int t0 = s_w[0], t1 = s_w[1], t2 = s_w[2], t3 = s_w[3];
+    const int base = w == 0 ? 0 : (w == 1 ? t0 : (w == 2 ? t0 + t1 : t0 + t1 + t2));
+    *total = t0 + t1 + t2 + t3;
+    __syncthreads();
+    return inc - v + base;
+}
+
+__global__ __launch_bounds__(256) void k_lil_pair(const float* __restrict__ lines, size_t lstride, int lp, const int* __restrict__ nlines, int nlines_single,
+                                                   float radius, float fanThr, int imgCols, int imgRows, float* __restrict__ raw,
+                                                   float* __restrict__ fans, int fan_cap, int* __restrict__ nfans) {
+    __shared__ int s_w[4];
+    const int frame = blockIdx.x, tid = threadIdx.x;
+    const float* L = lines + (size_t)frame * lstride;
+    const int rows = nlines ? nlines[frame] : nlines_single;
+    float* R = raw + (size_t)frame * PSL_FAN_CAP * 4;
+    int count = 0;
+    for (int i = 0; i < rows; ++i) {
+        const float p0 = L[lp * i], p1 = L[lp * i + 1], p2 = L[lp * i + 2], p3 = L[lp * i + 3];
+        const float cenx = PSL_FADD(p0, p2) / 2, ceny = PSL_FADD(p1, p3) / 2;
+        const float dy = PSL_FSUB(p3, p1), dx = PSL_FSUB(p2, p0);
+        const float degAng = psl_fast_atan2(dy, dx);
+        const float arcAng = (float)PSL_DMUL((double)(degAng / 180), PSL_PI);
+        const float length = __builtin_fabsf(tanf(arcAng)) > 1 ? __builtin_fabsf(dy) : __builtin_fabsf(dx);
+        const int th = (int)PSL_FMUL(radius, 2.f), tw = (int)PSL_FADD(length, PSL_FMUL(2.f, radius));  // CvSize is integer
+        const float hafW = (float)tw / 2, hafH = (float)th / 2;
+        const float angle = (float)(PSL_DMUL((double)degAng, PSL_PI) / 180);
+        float dsin, dcos;
+        psl_sincosf(angle, &dsin, &dcos);
+        const float gx = (float)PSL_DSUB(PSL_DMUL(-(double)cenx, (double)dcos), PSL_DMUL((double)ceny, (double)dsin));
+        const float gy = (float)PSL_DADD(PSL_DMUL(-(double)cenx, (double)dsin), PSL_DMUL((double)ceny, (double)dcos));
+        const float ndcos = -dcos;
+        for (int base = 0; base < 2 * rows; base += 256) {
+            const int pj = base + tid;
+            bool keep = false;
+            float X = 0, Y = 0;
+            int curSer = 0;
+            if (pj < 2 * rows) {
+                const float px = pj < rows ? L[lp * pj] : L[lp * (pj - rows) + 2];
+                const float py = pj < rows ? L[lp * pj + 1] : L[lp * (pj - rows) + 3];
+                const float fposx = PSL_FADD(PSL_FADD(PSL_FMUL(px, dcos), PSL_FMUL(py, dsin)), gx);
+                const float fposy = PSL_FADD(PSL_FADD(PSL_FMUL(px, dsin), PSL_FMUL(py, ndcos)), gy);
+                curSer = pj >= rows ? pj - rows : pj;
+                if (-hafW <= fposx && fposx < hafW && -hafH <= fposy && fposy < hafH && curSer != i) {
+                    const float q0 = L[lp * curSer], q1 = L[lp * curSer + 1], q2 = L[lp * curSer + 2], q3 = L[lp * curSer + 3];
+                    const float degAng1 = psl_fast_atan2(PSL_FSUB(q3, q1), PSL_FSUB(q2, q0));
+                    const float arcAng1 = (float)PSL_DMUL((double)(degAng1 / 180), PSL_PI);
+                    const float tmpa = fmodf(__builtin_fabsf(PSL_FSUB(arcAng, arcAng1)), (float)PSL_PI);
+                    if (!(tmpa < fanThr || PSL_DSUB(PSL_PI, (double)tmpa) < (double)fanThr)) {
+                        // intersectionOfLines (:226-247)
+                        const float A1 = PSL_FSUB(p1, p3), B1 = PSL_FSUB(p2, p0), C1 = PSL_FSUB(PSL_FMUL(p3, p0), PSL_FMUL(p1, p2));
+                        const float A2 = PSL_FSUB(q1, q3), B2 = PSL_FSUB(q2, q0), C2 = PSL_FSUB(PSL_FMUL(q3, q0), PSL_FMUL(q1, q2));
+                        const float D = (float)psl_det2(A1, B1, A2, B2);
+                        X = (float)(psl_det2(-C1, B1, -C2, B2) / (double)D);
+                        Y = (float)(psl_det2(A1, -C1, A2, -C2) / (double)D);
+                        // isPtInRotatedRect (:135-149), scalar float arithmetic
+                        const float fx = PSL_FADD(PSL_FMUL(dcos, PSL_FSUB(X, cenx)), PSL_FMUL(dsin, PSL_FSUB(Y, ceny)));
+                        const float fy = PSL_FSUB(PSL_FMUL(dsin, PSL_FSUB(X, cenx)), PSL_FMUL(dcos, PSL_FSUB(Y, ceny)));
+                        keep = (-hafW <= fx && fx < hafW && -hafH <= fy && fy < hafH) &&
+                               (X >= 4 && X < imgCols - 4 && Y >= 4 && Y < imgRows - 4);
+                    }
+                }
+            }
+            int tot;
+            const int ofs = psl_block_excl_scan256(keep ? 1 : 0, s_w, &tot);
+            if (keep && count + ofs < PSL_FAN_CAP) {
+                float* r = R + 4 * (size_t)(count + ofs);
+                r[0] = X; r[1] = Y; r[2] = (float)i; r[3] = (float)curSer;
+            }
+            count += tot;
+        }
+    }
+    if (count > PSL_FAN_CAP) count = PSL_FAN_CAP;
+    __syncthreads();
+    // keep the LAST occurrence of every unordered (i, j) pair (:109-131), order preserved
+    float* F = fans + (size_t)frame * fan_cap * 4;
+    int kept = 0;
+    for (int base = 0; base < count; base += 256) {
+        const int r = base + tid;
+        bool flag = false;
+        if (r < count) {
+            const int s1 = (int)R[4 * r + 2], s2 = (int)R[4 * r + 3];
+            flag = true;
+            for (int j = r + 1; j < count; ++j) {
+                const int s3 = (int)R[4 * j + 2], s4 = (int)R[4 * j + 3];
+                if ((s1 == s3 && s2 == s4) || (s1 == s4 && s2 == s3)) { flag = false; break; }
+            }
+        }
+        int tot;
+        const int ofs = psl_block_excl_scan256(flag ? 1 : 0, s_w, &tot);
+        if (flag && kept + ofs < fan_cap) {
+            float* d = F + 4 * (size_t)(kept + ofs);
+            d[0] = R[4 * r]; d[1] = R[4 * r + 1]; d[2] = R[4 * r + 2]; d[3] = R[4 * r + 3];
+        }
+        kept += tot;
+    }
+    if (tid == 0) nfans[frame] = kept < fan_cap ? kept : fan_cap;
+}
+
+#endif

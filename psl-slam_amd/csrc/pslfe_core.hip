@@ -134,4 +134,37 @@ int pslfe_ctx_stage_time(pslfe_ctx* ctx, const char* stage, double* ms_total, in
     return PSLFE_OK;
 }
 
+
+// ---- plain HBM helpers for callers that do not bring their own device allocator ------------------
+int pslfe_device_alloc(pslfe_ctx* ctx, size_t bytes, void** d_ptr) {
+    PSL_REQUIRE(ctx && d_ptr, PSLFE_E_INVALID, "pslfe_device_alloc: NULL argument");
+    PSL_HIP(hipSetDevice(ctx->device));
+    PSL_HIP(hipMalloc(d_ptr, bytes ? bytes : 1));
+    return PSLFE_OK;
+}
+
+int pslfe_device_free(pslfe_ctx* ctx, void* d_ptr) {
+    PSL_REQUIRE(ctx, PSLFE_E_INVALID, "pslfe_device_free: ctx is NULL");
+    PSL_HIP(hipSetDevice(ctx->device));
+    PSL_HIP(hipStreamSynchronize(ctx->stream));
+    PSL_HIP(hipFree(d_ptr));
+    return PSLFE_OK;
+}
+
+int pslfe_device_upload(pslfe_ctx* ctx, void* d_dst, const void* src, size_t bytes) {
+    PSL_REQUIRE(ctx && d_dst && src, PSLFE_E_INVALID, "pslfe_device_upload: NULL argument");
+    PSL_HIP(hipSetDevice(ctx->device));
+    PSL_HIP(hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    PSL_HIP(hipStreamSynchronize(ctx->stream));
+    return PSLFE_OK;
+}
+
+int pslfe_device_download(pslfe_ctx* ctx, void* dst, const void* d_src, size_t bytes) {
+    PSL_REQUIRE(ctx && dst && d_src, PSLFE_E_INVALID, "pslfe_device_download: NULL argument");
+    PSL_HIP(hipSetDevice(ctx->device));
+    PSL_HIP(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    PSL_HIP(hipStreamSynchronize(ctx->stream));
+    return PSLFE_OK;
+}
+
 }  // extern "C"

@@ -6,7 +6,7 @@
 #include <algorithm>
 #include <vector>
 
-#include "line_kernels.h"
+#include "line_kernels2.h"
 #include "pslfe_internal.h"
 
 struct pslfe_line {
@@ -30,8 +30,29 @@ struct pslfe_line {
     uint32_t* d_reg = nullptr;
     float* d_seg = nullptr;
     int* d_nseg = nullptr;
+    MergeScratch M = {};
+    PslKeyLine* d_kls = nullptr;
+    uint8_t* d_ldesc = nullptr;
+    float* d_fdesc = nullptr;
+    double* d_lineEq = nullptr;
+    int* d_nkl = nullptr;
+    int* d_status = nullptr;
+    uint8_t* d_lbdblur = nullptr;
+    short* d_dx = nullptr;
+    short* d_dy = nullptr;
+    float* d_rawfans = nullptr;
+    float* d_fans = nullptr;
+    int* d_nfans = nullptr;
+    float* d_tmplines = nullptr;  // [NMAX][4] staging for the host-pointer pairing entry point
 
     void release() {
+        hipFree(M.lines0); hipFree(M.lines1); hipFree(M.merged); hipFree(M.angles); hipFree(M.length); hipFree(M.order); hipFree(M.pos);
+        hipFree(M.adj); hipFree(M.code); hipFree(M.clist); hipFree(M.coff); hipFree(M.work); hipFree(M.bits); hipFree(M.stage);
+        M = MergeScratch{};
+        hipFree(d_kls); hipFree(d_ldesc); hipFree(d_fdesc); hipFree(d_lineEq); hipFree(d_nkl); hipFree(d_status); hipFree(d_lbdblur);
+        hipFree(d_dx); hipFree(d_dy); hipFree(d_rawfans); hipFree(d_fans); hipFree(d_nfans); hipFree(d_tmplines);
+        d_kls = nullptr; d_ldesc = nullptr; d_fdesc = nullptr; d_lineEq = nullptr; d_nkl = nullptr; d_status = nullptr; d_lbdblur = nullptr;
+        d_dx = nullptr; d_dy = nullptr; d_rawfans = nullptr; d_fans = nullptr; d_nfans = nullptr; d_tmplines = nullptr;
         hipFree(d_in); hipFree(d_scaled); hipFree(d_angdeg); hipFree(d_modgrad); hipFree(d_used); hipFree(d_reg);
         hipFree(d_seg); hipFree(d_nseg);
         d_in = nullptr; d_scaled = nullptr; d_angdeg = nullptr; d_modgrad = nullptr; d_used = nullptr; d_reg = nullptr;
@@ -46,7 +67,7 @@ struct pslfe_line {
         Q.w = w; Q.h = h;
         Q.W = (int)nearbyint(w * 0.8);
         Q.H = (int)nearbyint(h * 0.8);
-        Q.maxseg = 8192;
+        Q.maxseg = PSL_MERGE_NMAX;
         Q.maxkl = 2048;
         Q.nfeatures = nfeatures;
         {   // getGaussianKernel(7, 0.75, CV_64F): sigma = SIGMA_SCALE / SCALE, ksize = 1 + 2*ceil(sigma*sqrt(2*3*ln 10))
@@ -92,6 +113,34 @@ struct pslfe_line {
         PSL_HIP(hipMalloc((void**)&d_reg, npx * F * sizeof(uint32_t)));
         PSL_HIP(hipMalloc((void**)&d_seg, (size_t)Q.maxseg * 4 * sizeof(float) * F));
         PSL_HIP(hipMalloc((void**)&d_nseg, F * sizeof(int)));
+        const size_t N = PSL_MERGE_NMAX;
+        PSL_HIP(hipMalloc((void**)&M.lines0, F * N * 4 * sizeof(float)));
+        PSL_HIP(hipMalloc((void**)&M.lines1, F * N * 4 * sizeof(float)));
+        PSL_HIP(hipMalloc((void**)&M.merged, F * N * 4 * sizeof(float)));
+        PSL_HIP(hipMalloc((void**)&M.angles, F * N * sizeof(float)));
+        PSL_HIP(hipMalloc((void**)&M.length, F * N * sizeof(float)));
+        PSL_HIP(hipMalloc((void**)&M.order, F * N * sizeof(int)));
+        PSL_HIP(hipMalloc((void**)&M.pos, F * N * sizeof(int)));
+        PSL_HIP(hipMalloc((void**)&M.adj, F * N * (N / 32) * sizeof(uint32_t)));
+        PSL_HIP(hipMalloc((void**)&M.code, F * N * sizeof(int)));
+        PSL_HIP(hipMalloc((void**)&M.clist, F * PSL_MERGE_CLMAX * sizeof(int)));
+        PSL_HIP(hipMalloc((void**)&M.coff, F * (2 * N + 2) * sizeof(int)));
+        PSL_HIP(hipMalloc((void**)&M.work, F * 4 * N * sizeof(int)));
+        PSL_HIP(hipMalloc((void**)&M.bits, F * (N / 32) * sizeof(uint32_t)));
+        PSL_HIP(hipMalloc((void**)&M.stage, F * N * sizeof(PslKeyLine)));
+        PSL_HIP(hipMalloc((void**)&d_kls, F * Q.maxkl * sizeof(PslKeyLine)));
+        PSL_HIP(hipMalloc((void**)&d_ldesc, F * Q.maxkl * 32));
+        PSL_HIP(hipMalloc((void**)&d_fdesc, F * Q.maxkl * 72 * sizeof(float)));
+        PSL_HIP(hipMalloc((void**)&d_lineEq, F * Q.maxkl * 3 * sizeof(double)));
+        PSL_HIP(hipMalloc((void**)&d_nkl, F * sizeof(int)));
+        PSL_HIP(hipMalloc((void**)&d_status, F * sizeof(int)));
+        PSL_HIP(hipMalloc((void**)&d_lbdblur, F * (size_t)w * h));
+        PSL_HIP(hipMalloc((void**)&d_dx, F * (size_t)w * h * sizeof(short)));
+        PSL_HIP(hipMalloc((void**)&d_dy, F * (size_t)w * h * sizeof(short)));
+        PSL_HIP(hipMalloc((void**)&d_rawfans, F * PSL_FAN_CAP * 4 * sizeof(float)));
+        PSL_HIP(hipMalloc((void**)&d_fans, F * PSL_FAN_CAP * 4 * sizeof(float)));
+        PSL_HIP(hipMalloc((void**)&d_nfans, F * sizeof(int)));
+        PSL_HIP(hipMalloc((void**)&d_tmplines, N * 4 * sizeof(float)));
         P = Q;
         gw = w; gh = h;
         last_nframes = 0;
@@ -122,6 +171,49 @@ struct pslfe_line {
         }
         PSL_HIP(hipGetLastError());
         last_nframes = nframes;
+        return PSLFE_OK;
+    }
+
+    // optimizeAndMergeLines_lsd + KeyLines + top-N + line equations on the segment lists in d_seg/d_nseg
+    int run_merge(int nframes) {
+        PSL_HIP(hipSetDevice(ctx->device));
+        PSL_STAGE_BEGIN(ctx, "line.merge");
+        k_line_merge<<<nframes, 256, 0, ctx->stream>>>(P, M, d_seg, d_nseg, d_kls, d_lineEq, d_nkl, d_status);
+        PSL_STAGE_END(ctx, "line.merge");
+        PSL_HIP(hipGetLastError());
+        return PSLFE_OK;
+    }
+
+    // BinaryDescriptor::compute on the keylines in d_kls/d_nkl
+    int run_lbd(const uint8_t* d_gray, int nframes, int stride, size_t frame_stride, bool want_float) {
+        PSL_HIP(hipSetDevice(ctx->device));
+        hipStream_t st = ctx->stream;
+        dim3 grid((P.w + 63) / 64, (P.h + 3) / 4, nframes);
+        {
+            PSL_STAGE_BEGIN(ctx, "line.lbd_pre");
+            k_lbd_blur5<<<grid, 256, 0, st>>>(P, d_gray, stride, frame_stride, d_lbdblur);
+            k_lbd_sobel<<<grid, 256, 0, st>>>(P, d_lbdblur, d_dx, d_dy);
+            PSL_STAGE_END(ctx, "line.lbd_pre");
+        }
+        {
+            PSL_STAGE_BEGIN(ctx, "line.lbd");
+            const int per_frame = std::min(P.maxkl, std::max(P.nfeatures, 1));
+            k_lbd<<<dim3((per_frame + 3) / 4, nframes), 256, 0, st>>>(P, d_dx, d_dy, d_kls, d_nkl, d_ldesc, want_float ? d_fdesc : nullptr);
+            PSL_STAGE_END(ctx, "line.lbd");
+        }
+        PSL_HIP(hipGetLastError());
+        return PSLFE_OK;
+    }
+
+    int run_pair(int nframes, float radius, float fanThr) {
+        PSL_HIP(hipSetDevice(ctx->device));
+        PSL_STAGE_BEGIN(ctx, "line.pair");
+        // mLines = (startPointX, startPointY, endPointX, endPointY) of every keyline (src/Frame.cc:355-373):
+        // these are 4 consecutive floats at offset 7 of the 17-word KeyLine record
+        k_lil_pair<<<nframes, 256, 0, ctx->stream>>>(reinterpret_cast<const float*>(d_kls) + 7, (size_t)P.maxkl * 17, 17, d_nkl, 0, radius, fanThr,
+                                                     P.w, P.h, d_rawfans, d_fans, PSL_FAN_CAP, d_nfans);
+        PSL_STAGE_END(ctx, "line.pair");
+        PSL_HIP(hipGetLastError());
         return PSLFE_OK;
     }
 
@@ -212,6 +304,178 @@ int pslfe_line_debug_gradient(pslfe_line* line, int frame, int* W, int* H, doubl
     if (scaled) PSL_HIP(hipMemcpy(scaled, line->d_scaled + frame * npx, npx * sizeof(double), hipMemcpyDeviceToHost));
     if (angle_deg) PSL_HIP(hipMemcpy(angle_deg, line->d_angdeg + frame * npx, npx * sizeof(float), hipMemcpyDeviceToHost));
     if (modgrad) PSL_HIP(hipMemcpy(modgrad, line->d_modgrad + frame * npx, npx * sizeof(double), hipMemcpyDeviceToHost));
+    return PSLFE_OK;
+}
+
+
+// ---- full extractor ------------------------------------------------------------------------------
+int pslfe_line_extract_batch_device(pslfe_line* line, const uint8_t* d_gray, int nframes, int w, int h, int stride, size_t frame_stride) {
+    PSL_REQUIRE(line && d_gray, PSLFE_E_INVALID, "pslfe_line_extract_batch_device: NULL argument");
+    PSL_REQUIRE(nframes >= 1 && nframes <= line->max_batch, PSLFE_E_INVALID, "pslfe_line_extract_batch_device: nframes %d (max_batch %d)", nframes, line->max_batch);
+    PSL_REQUIRE(stride >= w && (nframes == 1 || frame_stride >= (size_t)stride * h), PSLFE_E_INVALID, "pslfe_line_extract_batch_device: strides");
+    int rc = line->run_lsd(d_gray, nframes, w, h, stride, frame_stride);
+    if (rc) return rc;
+    if ((rc = line->run_merge(nframes))) return rc;
+    return line->run_lbd(d_gray, nframes, stride, frame_stride, false);
+}
+
+int pslfe_line_results_device(pslfe_line* line, const PslKeyLine** d_kls, const uint8_t** d_desc, const double** d_lineEq,
+                              const int32_t** d_counts, int* kl_cap) {
+    PSL_REQUIRE(line, PSLFE_E_INVALID, "pslfe_line_results_device: line is NULL");
+    PSL_REQUIRE(line->last_nframes > 0, PSLFE_E_STATE, "pslfe_line_results_device: no batch extracted yet");
+    if (d_kls) *d_kls = line->d_kls;
+    if (d_desc) *d_desc = line->d_ldesc;
+    if (d_lineEq) *d_lineEq = line->d_lineEq;
+    if (d_counts) *d_counts = line->d_nkl;
+    if (kl_cap) *kl_cap = line->P.maxkl;
+    return PSLFE_OK;
+}
+
+int pslfe_line_fetch(pslfe_line* line, int frame, PslKeyLine* kls, uint8_t* desc, double* lineEq, int cap, int* n, int* status) {
+    PSL_REQUIRE(line && n, PSLFE_E_INVALID, "pslfe_line_fetch: NULL argument");
+    PSL_REQUIRE(line->last_nframes > 0 && frame >= 0 && frame < line->last_nframes, PSLFE_E_STATE, "pslfe_line_fetch: frame %d", frame);
+    PSL_HIP(hipSetDevice(line->ctx->device));
+    hipStream_t st = line->ctx->stream;
+    int cnt = 0, stt = 0;
+    PSL_HIP(hipMemcpyAsync(&cnt, line->d_nkl + frame, sizeof(int), hipMemcpyDeviceToHost, st));
+    PSL_HIP(hipMemcpyAsync(&stt, line->d_status + frame, sizeof(int), hipMemcpyDeviceToHost, st));
+    PSL_HIP(hipStreamSynchronize(st));
+    *n = cnt;
+    if (status) *status = stt;
+    PSL_REQUIRE(cnt <= cap, PSLFE_E_CAPACITY, "pslfe_line_fetch: %d keylines, capacity %d", cnt, cap);
+    if (cnt > 0) {
+        const size_t o = (size_t)frame * line->P.maxkl;
+        if (kls) PSL_HIP(hipMemcpyAsync(kls, line->d_kls + o, (size_t)cnt * sizeof(PslKeyLine), hipMemcpyDeviceToHost, st));
+        if (desc) PSL_HIP(hipMemcpyAsync(desc, line->d_ldesc + o * 32, (size_t)cnt * 32, hipMemcpyDeviceToHost, st));
+        if (lineEq) PSL_HIP(hipMemcpyAsync(lineEq, line->d_lineEq + o * 3, (size_t)cnt * 3 * sizeof(double), hipMemcpyDeviceToHost, st));
+        PSL_HIP(hipStreamSynchronize(st));
+    }
+    return PSLFE_OK;
+}
+
+int pslfe_line_extract(pslfe_line* line, const uint8_t* gray, int w, int h, int stride, PslKeyLine* kls, uint8_t* desc, double* lineEq,
+                       int cap, int* n) {
+    PSL_REQUIRE(line && n, PSLFE_E_INVALID, "pslfe_line_extract: NULL argument");
+    *n = 0;
+    if (!gray || w <= 0 || h <= 0) return PSLFE_OK;  // add_src/LineExtractor.cpp:327: empty image -> silent return
+    PSL_REQUIRE(stride >= w, PSLFE_E_INVALID, "pslfe_line_extract: stride %d < width %d", stride, w);
+    int rc = line->upload(gray, 1, w, h, stride, (size_t)stride * h);
+    if (rc) return rc;
+    rc = pslfe_line_extract_batch_device(line, line->d_in, 1, w, h, line->in_pitch, line->in_fstride);
+    if (rc) return rc;
+    return pslfe_line_fetch(line, 0, kls, desc, lineEq, cap, n, nullptr);
+}
+
+// ---- stage entry points (also used by the parity tests) ---------------------------------------------
+int pslfe_line_optimize_and_merge(pslfe_line* line, const float* segments, int nseg, int w, int h, PslKeyLine* kls, int cap, int* n) {
+    PSL_REQUIRE(line && n && (nseg == 0 || segments), PSLFE_E_INVALID, "pslfe_line_optimize_and_merge: NULL argument");
+    *n = 0;
+    PSL_REQUIRE(nseg >= 0 && nseg <= PSL_MERGE_NMAX, PSLFE_E_CAPACITY, "pslfe_line_optimize_and_merge: %d segments (max %d)", nseg, PSL_MERGE_NMAX);
+    int rc = line->prepare(w, h);
+    if (rc) return rc;
+    PSL_HIP(hipSetDevice(line->ctx->device));
+    hipStream_t st = line->ctx->stream;
+    if (nseg) PSL_HIP(hipMemcpyAsync(line->d_seg, segments, (size_t)nseg * 4 * sizeof(float), hipMemcpyHostToDevice, st));
+    PSL_HIP(hipMemcpyAsync(line->d_nseg, &nseg, sizeof(int), hipMemcpyHostToDevice, st));
+    PSL_HIP(hipStreamSynchronize(st));
+    // the top-N cut belongs to LINEextractor::operator(); this entry point is optimizeAndMergeLines_lsd alone
+    const int keep = line->P.nfeatures;
+    line->P.nfeatures = line->P.maxkl;
+    rc = line->run_merge(1);
+    line->P.nfeatures = keep;
+    if (rc) return rc;
+    line->last_nframes = 1;
+    return pslfe_line_fetch(line, 0, kls, nullptr, nullptr, cap, n, nullptr);
+}
+
+int pslfe_lbd_compute(pslfe_line* line, const uint8_t* gray, int w, int h, int stride, const PslKeyLine* kls, int nkl, uint8_t* desc,
+                      float* fdesc) {
+    PSL_REQUIRE(line && gray && (nkl == 0 || (kls && desc)), PSLFE_E_INVALID, "pslfe_lbd_compute: NULL argument");
+    if (nkl == 0) return PSLFE_OK;  // upstream prints "keypoint list is empty" and returns (binary_descriptor_custom.cpp:559-563)
+    PSL_REQUIRE(stride >= w, PSLFE_E_INVALID, "pslfe_lbd_compute: stride %d < width %d", stride, w);
+    int rc = line->upload(gray, 1, w, h, stride, (size_t)stride * h);
+    if (rc) return rc;
+    PSL_REQUIRE(nkl <= line->P.maxkl, PSLFE_E_CAPACITY, "pslfe_lbd_compute: %d keylines (max %d)", nkl, line->P.maxkl);
+    hipStream_t st = line->ctx->stream;
+    PSL_HIP(hipMemcpyAsync(line->d_kls, kls, (size_t)nkl * sizeof(PslKeyLine), hipMemcpyHostToDevice, st));
+    PSL_HIP(hipMemcpyAsync(line->d_nkl, &nkl, sizeof(int), hipMemcpyHostToDevice, st));
+    PSL_HIP(hipStreamSynchronize(st));
+    const int keep = line->P.nfeatures;
+    line->P.nfeatures = std::max(keep, nkl);
+    rc = line->run_lbd(line->d_in, 1, line->in_pitch, line->in_fstride, fdesc != nullptr);
+    line->P.nfeatures = keep;
+    if (rc) return rc;
+    PSL_HIP(hipMemcpyAsync(desc, line->d_ldesc, (size_t)nkl * 32, hipMemcpyDeviceToHost, st));
+    if (fdesc) PSL_HIP(hipMemcpyAsync(fdesc, line->d_fdesc, (size_t)nkl * 72 * sizeof(float), hipMemcpyDeviceToHost, st));
+    PSL_HIP(hipStreamSynchronize(st));
+    line->last_nframes = 1;
+    return PSLFE_OK;
+}
+
+int pslfe_line_debug_sobel(pslfe_line* line, int frame, int16_t* dx, int16_t* dy) {
+    PSL_REQUIRE(line && dx && dy, PSLFE_E_INVALID, "pslfe_line_debug_sobel: NULL argument");
+    PSL_REQUIRE(line->last_nframes > 0 && frame >= 0 && frame < line->last_nframes, PSLFE_E_STATE, "pslfe_line_debug_sobel: frame %d", frame);
+    PSL_HIP(hipSetDevice(line->ctx->device));
+    PSL_HIP(hipStreamSynchronize(line->ctx->stream));
+    const size_t npx = (size_t)line->P.w * line->P.h;
+    PSL_HIP(hipMemcpy(dx, line->d_dx + frame * npx, npx * sizeof(short), hipMemcpyDeviceToHost));
+    PSL_HIP(hipMemcpy(dy, line->d_dy + frame * npx, npx * sizeof(short), hipMemcpyDeviceToHost));
+    return PSLFE_OK;
+}
+
+// == CPartiallyRecoverConnectivity(mLines, radius, fans, img, fanThr): host matrix in, fans rows out
+int pslfe_lil_pair(pslfe_line* line, const float* lines, int nlines, float radius, float fanThr, int imgCols, int imgRows, float* fans,
+                   int cap, int* nfans) {
+    PSL_REQUIRE(line && nfans && (nlines == 0 || lines), PSLFE_E_INVALID, "pslfe_lil_pair: NULL argument");
+    *nfans = 0;
+    if (nlines == 0) return PSLFE_OK;
+    PSL_REQUIRE(nlines <= PSL_MERGE_NMAX, PSLFE_E_CAPACITY, "pslfe_lil_pair: %d lines (max %d)", nlines, PSL_MERGE_NMAX);
+    int rc = line->prepare(line->gw > 0 ? line->gw : std::max(imgCols, 16), line->gh > 0 ? line->gh : std::max(imgRows, 16));
+    if (rc) return rc;
+    PSL_HIP(hipSetDevice(line->ctx->device));
+    hipStream_t st = line->ctx->stream;
+    PSL_HIP(hipMemcpyAsync(line->d_tmplines, lines, (size_t)nlines * 4 * sizeof(float), hipMemcpyHostToDevice, st));
+    PSL_HIP(hipStreamSynchronize(st));
+    {
+        PSL_STAGE_BEGIN(line->ctx, "line.pair");
+        k_lil_pair<<<1, 256, 0, st>>>(line->d_tmplines, 0, 4, nullptr, nlines, radius, fanThr, imgCols, imgRows, line->d_rawfans, line->d_fans,
+                                      PSL_FAN_CAP, line->d_nfans);
+        PSL_STAGE_END(line->ctx, "line.pair");
+    }
+    PSL_HIP(hipGetLastError());
+    int k = 0;
+    PSL_HIP(hipMemcpyAsync(&k, line->d_nfans, sizeof(int), hipMemcpyDeviceToHost, st));
+    PSL_HIP(hipStreamSynchronize(st));
+    *nfans = k;
+    PSL_REQUIRE(k <= cap, PSLFE_E_CAPACITY, "pslfe_lil_pair: %d fans, capacity %d", k, cap);
+    if (k > 0 && fans) {
+        PSL_HIP(hipMemcpyAsync(fans, line->d_fans, (size_t)k * 4 * sizeof(float), hipMemcpyDeviceToHost, st));
+        PSL_HIP(hipStreamSynchronize(st));
+    }
+    return PSLFE_OK;
+}
+
+// Pairing of every frame of the last extracted batch, HBM resident (mLines = keyline endpoints, src/Frame.cc:504-505)
+int pslfe_line_pair_batch_device(pslfe_line* line, float radius, float fanThr) {
+    PSL_REQUIRE(line, PSLFE_E_INVALID, "pslfe_line_pair_batch_device: line is NULL");
+    PSL_REQUIRE(line->last_nframes > 0, PSLFE_E_STATE, "pslfe_line_pair_batch_device: no batch extracted yet");
+    return line->run_pair(line->last_nframes, radius, fanThr);
+}
+
+int pslfe_line_fans_fetch(pslfe_line* line, int frame, float* fans, int cap, int* nfans) {
+    PSL_REQUIRE(line && nfans, PSLFE_E_INVALID, "pslfe_line_fans_fetch: NULL argument");
+    PSL_REQUIRE(line->last_nframes > 0 && frame >= 0 && frame < line->last_nframes, PSLFE_E_STATE, "pslfe_line_fans_fetch: frame %d", frame);
+    PSL_HIP(hipSetDevice(line->ctx->device));
+    hipStream_t st = line->ctx->stream;
+    int k = 0;
+    PSL_HIP(hipMemcpyAsync(&k, line->d_nfans + frame, sizeof(int), hipMemcpyDeviceToHost, st));
+    PSL_HIP(hipStreamSynchronize(st));
+    *nfans = k;
+    PSL_REQUIRE(k <= cap, PSLFE_E_CAPACITY, "pslfe_line_fans_fetch: %d fans, capacity %d", k, cap);
+    if (k > 0 && fans) {
+        PSL_HIP(hipMemcpyAsync(fans, line->d_fans + (size_t)frame * PSL_FAN_CAP * 4, (size_t)k * 4 * sizeof(float), hipMemcpyDeviceToHost, st));
+        PSL_HIP(hipStreamSynchronize(st));
+    }
     return PSLFE_OK;
 }
 

@@ -62,3 +62,148 @@ def test_lsd_segments(style, seed):
 def test_lsd_flat_image_gives_no_segments():
     import psl_slam_amd as P
     assert len(P.LINEextractor().lsd_detect(np.full((480, 640), 128, np.uint8))) == 0
+
+
+def _kl_equal(a, b, what, skip=()):
+    assert len(a) == len(b), f"{what}: {len(a)} vs {len(b)} keylines"
+    for name in a.dtype.names:
+        if name in skip:
+            continue
+        x, y = a[name], b[name]
+        bad = np.flatnonzero(x.view(np.uint32) != y.view(np.uint32)) if x.dtype.kind == "f" else np.flatnonzero(x != y)
+        assert bad.size == 0, f"{what}: field {name} differs at {bad[:5]}: {x[bad[:5]]} vs {y[bad[:5]]}"
+
+
+@pytest.mark.parametrize("style,seed", [("struct", 3), ("desk", 4), ("struct", 8)])
+def test_merge_stage_on_oracle_segments(style, seed):
+    """optimizeAndMergeLines_lsd on identical input segments.  The merge uses atanf / atan2f / double
+    sin, cos from the device math library vs glibc in the oracle (last-ulp differences possible), so
+    the contract is a tolerance: same number of lines, endpoints within 0.01 px; bit-identity is
+    reported."""
+    import psl_slam_amd as P
+    import oracle_lib
+    img = _scene(style, seed)
+    seg = oracle_lib.lsd_detect(img)
+    ref = oracle_lib.optimize_and_merge(seg, 640, 480)
+    got = P.LINEextractor().optimize_and_merge(seg, 640, 480)
+    assert len(got) == len(ref) and len(ref) > 10
+    ge = np.stack([got[n] for n in ("startPointX", "startPointY", "endPointX", "endPointY")], 1)
+    re_ = np.stack([ref[n] for n in ("startPointX", "startPointY", "endPointX", "endPointY")], 1)
+    assert np.abs(ge - re_).max() <= 0.01
+    np.testing.assert_array_equal(got["numOfPixels"], ref["numOfPixels"])
+    np.testing.assert_array_equal(got["class_id"], ref["class_id"])
+    exact = got.tobytes() == ref.tobytes()
+    print(f"merge {style}/{seed}: {len(seg)} segments -> {len(got)} keylines, bit-identical {exact}")
+
+
+@pytest.mark.parametrize("style,seed", [("struct", 3), ("desk", 4)])
+def test_lbd_exact_on_oracle_keylines(style, seed):
+    """LBD given keylines: blur, Sobel, 72-float vector and the 256-bit code, all bit-exact."""
+    import psl_slam_amd as P
+    import oracle_lib
+    img = _scene(style, seed)
+    kls, rdesc, _ = oracle_lib.line_extract(img, 200)
+    le = P.LINEextractor()
+    desc, fdesc = le.lbd_compute(img, kls, want_float=True)
+    dx, dy = le.debug_sobel(640, 480)
+    rdx, rdy = oracle_lib.lbd_sobel(img)
+    np.testing.assert_array_equal(dx, rdx)
+    np.testing.assert_array_equal(dy, rdy)
+    rdesc2, rfdesc = oracle_lib.lbd_compute(img, kls, want_float=True)
+    np.testing.assert_array_equal(rdesc2, rdesc)
+    np.testing.assert_array_equal(fdesc.view(np.uint32), rfdesc.view(np.uint32))
+    np.testing.assert_array_equal(desc, rdesc)
+    assert len(kls) > 20
+
+
+def test_lbd_lines_touching_the_border():
+    import psl_slam_amd as P
+    import oracle_lib
+    img = _scene("desk", 12)
+    kls = np.zeros(4, P.KEYLINE_DTYPE)
+    ends = [(0, 0, 639, 479), (-20.5, 100.2, 300.7, -10.0), (620, 5, 700, 470), (5.5, 470.25, 630.25, 478.5)]
+    for i, (x1, y1, x2, y2) in enumerate(ends):
+        for a, b in (("startPointX", x1), ("startPointY", y1), ("endPointX", x2), ("endPointY", y2), ("sPointInOctaveX", x1),
+                     ("sPointInOctaveY", y1), ("ePointInOctaveX", x2), ("ePointInOctaveY", y2)):
+            kls[a][i] = b
+        kls["angle"][i] = np.float32(np.arctan2(np.float32(y2) - np.float32(y1), np.float32(x2) - np.float32(x1)))
+        kls["numOfPixels"][i] = oracle_lib.load().pso_line_iterator_count(640, 480, *[__import__("ctypes").c_float(v) for v in (x1, y1, x2, y2)])
+        kls["class_id"][i] = i
+    assert (kls["numOfPixels"] > 0).all()
+    desc, fdesc = P.LINEextractor().lbd_compute(img, kls, want_float=True)
+    rdesc, rfdesc = oracle_lib.lbd_compute(img, kls, want_float=True)
+    np.testing.assert_array_equal(fdesc.view(np.uint32), rfdesc.view(np.uint32))
+    np.testing.assert_array_equal(desc, rdesc)
+
+
+@pytest.mark.parametrize("style,seed", [("struct", 3), ("desk", 4), ("struct", 8)])
+def test_pairing_on_oracle_lines(style, seed):
+    import psl_slam_amd as P
+    import oracle_lib
+    img = _scene(style, seed)
+    kls, _, _ = oracle_lib.line_extract(img, 200)
+    lines = np.stack([kls[n] for n in ("startPointX", "startPointY", "endPointX", "endPointY")], 1).astype(np.float32)
+    ref = oracle_lib.lil_pair(lines, 20.0, np.float32(np.pi / 4), 640, 480)
+    got = P.LINEextractor().pair(lines, 20.0, np.float32(np.pi / 4), 640, 480)
+    assert got.shape == ref.shape and len(ref) > 5
+    np.testing.assert_array_equal(got[:, 2:], ref[:, 2:])
+    assert np.abs(got[:, :2] - ref[:, :2]).max() <= 1e-3
+    print(f"pairing {style}/{seed}: {len(ref)} fans, bit-identical {got.tobytes() == ref.tobytes()}")
+    # degenerate inputs: no lines, one line
+    assert len(P.LINEextractor().pair(np.zeros((0, 4), np.float32), 20.0, 0.785, 640, 480)) == 0
+    assert len(P.LINEextractor().pair(lines[:1], 20.0, 0.785, 640, 480)) == 0
+
+
+@pytest.mark.parametrize("style,seed", [("struct", 3), ("desk", 4), ("struct", 8)])
+def test_full_line_extractor(style, seed):
+    """LINEextractor::operator(): tolerance contract (SURVEY.md H8): >= 95 % of the oracle's keylines
+    recovered with endpoints within 0.5 px and, on the recovered ones, LBD Hamming distance <= 8."""
+    import psl_slam_amd as P
+    import oracle_lib
+    img = _scene(style, seed)
+    rk, rd, re_ = oracle_lib.line_extract(img, 200)
+    gk, gd, ge = P.LINEextractor(1, 1.2, 200, 0.0)(img)
+    assert len(rk) > 20 and abs(len(gk) - len(rk)) <= 0.05 * len(rk)
+    R = np.stack([rk[n] for n in ("startPointX", "startPointY", "endPointX", "endPointY")], 1)
+    G = np.stack([gk[n] for n in ("startPointX", "startPointY", "endPointX", "endPointY")], 1)
+    hit = 0
+    for i, r in enumerate(R):
+        d = np.abs(G - r).max(1)
+        j = int(d.argmin())
+        if d[j] <= 0.5:
+            hit += 1
+            assert int(np.unpackbits(gd[j] ^ rd[i]).sum()) <= 8
+            assert np.abs(ge[j] - re_[i]).max() <= 1e-2 * max(1.0, np.abs(re_[i]).max())
+    exact = gk.tobytes() == rk.tobytes() and (gd == rd).all() and ge.tobytes() == re_.tobytes()
+    print(f"line extract {style}/{seed}: {len(gk)} vs {len(rk)} keylines, recovered {hit / len(rk):.4f}, bit-identical {exact}")
+    assert hit >= 0.95 * len(rk)
+
+
+def test_line_extractor_batch_and_pairing_device():
+    import psl_slam_amd as P
+    frames = np.stack([_scene("struct", 3, t) for t in range(3)], 0)
+    le = P.LINEextractor(1, 1.2, 200, 0.0, max_batch=3)
+    d_ptr, _ = le.ctx.device_array(frames)
+    le.extract_batch_device(d_ptr, 3, 640, 480, 640, 640 * 480)
+    le.pair_batch_device(20.0, np.float32(np.pi / 4))
+    single = P.LINEextractor(1, 1.2, 200, 0.0)
+    for f in range(3):
+        k, dsc, eq, st = le.fetch(f)
+        k1, d1, e1 = single(frames[f])
+        assert st == 0 and k.tobytes() == k1.tobytes() and (dsc == d1).all() and eq.tobytes() == e1.tobytes()
+        lines = np.stack([k[n] for n in ("startPointX", "startPointY", "endPointX", "endPointY")], 1).astype(np.float32)
+        fans = le.fans_fetch(f)
+        ref = single.pair(lines, 20.0, np.float32(np.pi / 4), 640, 480)
+        assert fans.tobytes() == ref.tobytes()
+    le.ctx.device_free(d_ptr)
+
+
+def test_line_extractor_empty_inputs():
+    import psl_slam_amd as P
+    le = P.LINEextractor()
+    k, d, e = le(np.zeros((0, 0), np.uint8))
+    assert len(k) == 0
+    k, d, e = le(np.full((480, 640), 77, np.uint8))   # no gradients: LSD finds nothing; upstream would hit UB (H12)
+    assert len(k) == 0 and d.shape == (0, 32)
+    with pytest.raises(P.PslfeError):
+        P.LINEextractor(2, 1.2, 200, 0.0)              # only numOctaves == 1 (every reference YAML)
