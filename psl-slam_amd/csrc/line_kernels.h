@@ -95,20 +95,29 @@ __global__ __launch_bounds__(256) void k_lsd_scale(LineParams P, const uint8_t* 
 // LSD step 2 (ll_angle): 2x2 gradient, norm (f64, correctly rounded sqrt), level-line angle by the
 // f32 fastAtan2 polynomial.  The angle is stored as f32 degrees (the reference's double is exactly
 // double(deg) * DEG_TO_RADS, recomputed where it is used); NOTDEF = -1024.
+// Also tabulates, per pixel with a defined angle a = (double)deg * DEG_TO_RADS, the four values the
+// region-growing chain needs: cosf((float)a), sinf((float)a) (every pixel that joins a region) and
+// (float)cos(a), (float)sin(a) (the seed pixel), so that the serial chain contains no trigonometry.
 __global__ __launch_bounds__(256) void k_lsd_grad(LineParams P, const double* __restrict__ scaled, float* __restrict__ angdeg,
-                                                   double* __restrict__ modgrad) {
+                                                   double* __restrict__ modgrad, float4* __restrict__ trig) {
     const int frame = blockIdx.z;
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= P.W || y >= P.H) return;
     const size_t o = (size_t)frame * P.W * P.H + (size_t)y * P.W + x;
-    if (x == P.W - 1 || y == P.H - 1) { angdeg[o] = PSL_LSD_NOTDEF; modgrad[o] = 0.0; return; }
+    if (x == P.W - 1 || y == P.H - 1) { angdeg[o] = PSL_LSD_NOTDEF; modgrad[o] = 0.0; trig[o] = make_float4(0, 0, 0, 0); return; }
     const double* r0 = scaled + (size_t)frame * P.W * P.H + (size_t)y * P.W;
     const double* r1 = r0 + P.W;
     const double DA = PSL_DSUB(r1[x + 1], r0[x]), BC = PSL_DSUB(r0[x + 1], r1[x]);
     const double gx = PSL_DADD(DA, BC), gy = PSL_DSUB(DA, BC);
     const double norm = __dsqrt_rn(PSL_DADD(PSL_DMUL(gx, gx), PSL_DMUL(gy, gy)) / 4);
     modgrad[o] = norm;
-    angdeg[o] = norm <= P.rho ? PSL_LSD_NOTDEF : psl_fast_atan2((float)gx, (float)(-gy));
+    if (norm <= P.rho) { angdeg[o] = PSL_LSD_NOTDEF; trig[o] = make_float4(0, 0, 0, 0); return; }
+    const float deg = psl_fast_atan2((float)gx, (float)(-gy));
+    angdeg[o] = deg;
+    const double ad = PSL_DMUL((double)deg, PSL_DEG2RAD);
+    float sn, cs;
+    psl_sincosf((float)ad, &sn, &cs);
+    trig[o] = make_float4(cs, sn, (float)cos(ad), (float)sin(ad));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -323,6 +332,297 @@ __global__ __launch_bounds__(64) void k_lsd_grow(LineParams P, const float* __re
             ++count;
         }
     nseg[frame] = count < P.maxseg ? count : P.maxseg;
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// LSD steps 3-6, wave-parallel and still exact (k_lsd_grow2).  One wave owns one frame.
+//  * `used` map = bitmap in LDS;  the last 1024 queue entries are mirrored in an LDS ring;
+//  * seeds: 256 pixels per step (4 coalesced loads in flight), ballot -> first candidate;
+//  * region growing: up to 7 queue entries are popped together, lane = (entry, neighbour): the 63
+//    neighbour angles are loaded in ONE round trip and their cosf/sinf are evaluated speculatively in
+//    parallel; only the running-angle chain (add, fastAtan2) stays serial, in the reference's order;
+//  * sums whose rounding depends on the order (centroid, inertia, refine statistics) are formed as
+//    "terms in parallel, additions in series" (64 terms staged in LDS per step); min/max extents are
+//    order independent and use wave reductions.
+// Serial scalar logic is executed redundantly by all lanes (uniform values, no broadcasts); stores
+// are issued by lane 0.
+// ---------------------------------------------------------------------------------------------
+#define PSL_LSD_RING 1024
+
+struct LsdW {
+    int W, H, lane;
+    const float* ang;
+    const double* mod;
+    const float4* trig;
+    uint32_t* used;   // LDS bitmap
+    uint32_t* ring;   // LDS mirror of reg[idx & (RING-1)]
+    double* term;     // LDS [3][64]
+    uint32_t* reg;    // HBM queue
+};
+
+__device__ __forceinline__ bool lsdw_used(const LsdW& F, int a) { return (F.used[a >> 5] >> (a & 31)) & 1u; }
+__device__ __forceinline__ void lsdw_set(const LsdW& F, int a) { if (F.lane == 0) F.used[a >> 5] |= 1u << (a & 31); }
+__device__ __forceinline__ uint32_t lsdw_reg(const LsdW& F, int idx, int reg_size) {
+    return (reg_size - idx <= PSL_LSD_RING) ? F.ring[idx & (PSL_LSD_RING - 1)] : F.reg[idx];
+}
+__device__ __forceinline__ void lsdw_push(const LsdW& F, int idx, uint32_t v) {
+    if (F.lane == 0) { F.reg[idx] = v; F.ring[idx & (PSL_LSD_RING - 1)] = v; }
+}
+
+__device__ __forceinline__ bool lsdw_aligned(double ad, double theta, double prec) {
+    double n_theta = PSL_DSUB(theta, ad);
+    if (n_theta < 0) n_theta = -n_theta;
+    if (n_theta > (3 * PSL_PI) / 2) {
+        n_theta = PSL_DSUB(n_theta, 2 * PSL_PI);
+        if (n_theta < 0) n_theta = -n_theta;
+    }
+    return n_theta <= prec;
+}
+
+__device__ int lsdw_region_grow(const LsdW& F, int sx, int sy, double* reg_angle_out, double prec) {
+    int reg_size = 1;
+    const int addr0 = sx + sy * F.W;
+    lsdw_push(F, 0, (uint32_t)sx | ((uint32_t)sy << 16));
+    double reg_angle = PSL_DMUL((double)F.ang[addr0], PSL_DEG2RAD);
+    const float4 t0 = F.trig[addr0];
+    float sumdx = t0.z, sumdy = t0.w;  // float(cos(reg_angle)), float(sin(reg_angle))
+    lsdw_set(F, addr0);
+    const int e = F.lane / 9, k = F.lane - e * 9, ky = k / 3, kx = k - ky * 3;
+    int i = 0;
+    while (i < reg_size) {
+        const int nb = min(7, reg_size - i);
+        const bool act = F.lane < 63 && e < nb;
+        int c = 0, nx = 0, ny = 0;
+        float a = PSL_LSD_NOTDEF;
+        float sn = 0.f, cs = 0.f;
+        if (act) {
+            const uint32_t rp = lsdw_reg(F, i + e, reg_size);
+            nx = (int)(rp & 0xffff) + kx - 1;
+            ny = (int)(rp >> 16) + ky - 1;
+            if (nx >= 0 && nx < F.W && ny >= 0 && ny < F.H) {
+                c = nx + ny * F.W;
+                a = F.ang[c];
+                const float2 t = *reinterpret_cast<const float2*>(&F.trig[c]);  // cosf, sinf of this pixel's angle
+                cs = t.x; sn = t.y;
+            }
+        }
+        const bool cand0 = a != PSL_LSD_NOTDEF;
+        const double ad = PSL_DMUL((double)a, PSL_DEG2RAD);
+        for (int ee = 0; ee < nb; ++ee) {
+            int pos = 0;
+            while (true) {
+                const bool ok = cand0 && e == ee && k >= pos && !lsdw_used(F, c) && lsdw_aligned(ad, reg_angle, prec);
+                const unsigned long long m = __ballot(ok);
+                if (!m) break;
+                const int L = __ffsll((long long)m) - 1;
+                const int cL = __shfl(c, L), xL = __shfl(nx, L), yL = __shfl(ny, L);
+                const float csL = __shfl(cs, L), snL = __shfl(sn, L);
+                lsdw_set(F, cL);
+                lsdw_push(F, reg_size, (uint32_t)xL | ((uint32_t)yL << 16));
+                ++reg_size;
+                sumdx = PSL_FADD(sumdx, csL);
+                sumdy = PSL_FADD(sumdy, snL);
+                reg_angle = PSL_DMUL((double)psl_fast_atan2(sumdy, sumdx), PSL_DEG2RAD);
+                pos = (L - 9 * ee) + 1;
+            }
+        }
+        i += nb;
+    }
+    *reg_angle_out = reg_angle;
+    return reg_size;
+}
+
+__device__ __forceinline__ double lsdw_wave_max(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const double u = __shfl_xor(v, o); v = u > v ? u : v; }
+    return v;
+}
+__device__ __forceinline__ double lsdw_wave_min(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const double u = __shfl_xor(v, o); v = u < v ? u : v; }
+    return v;
+}
+
+__device__ void lsdw_region2rect(const LsdW& F, int reg_size, double reg_angle, double prec, LsdRect* rec) {
+    double x = 0, y = 0, sum = 0;
+    for (int base = 0; base < reg_size; base += 64) {
+        const int j = base + F.lane, cnt = min(64, reg_size - base);
+        if (j < reg_size) {
+            const uint32_t rp = lsdw_reg(F, j, reg_size);
+            const int px = (int)(rp & 0xffff), py = (int)(rp >> 16);
+            const double w = F.mod[px + py * F.W];
+            F.term[F.lane] = PSL_DMUL((double)px, w); F.term[64 + F.lane] = PSL_DMUL((double)py, w); F.term[128 + F.lane] = w;
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (int t = 0; t < cnt; ++t) { x = PSL_DADD(x, F.term[t]); y = PSL_DADD(y, F.term[64 + t]); sum = PSL_DADD(sum, F.term[128 + t]); }
+        __builtin_amdgcn_wave_barrier();
+    }
+    x = x / sum; y = y / sum;
+    double Ixx = 0, Iyy = 0, Ixy = 0;
+    for (int base = 0; base < reg_size; base += 64) {
+        const int j = base + F.lane, cnt = min(64, reg_size - base);
+        if (j < reg_size) {
+            const uint32_t rp = lsdw_reg(F, j, reg_size);
+            const int px = (int)(rp & 0xffff), py = (int)(rp >> 16);
+            const double w = F.mod[px + py * F.W];
+            const double dx = PSL_DSUB((double)px, x), dy = PSL_DSUB((double)py, y);
+            F.term[F.lane] = PSL_DMUL(PSL_DMUL(dy, dy), w); F.term[64 + F.lane] = PSL_DMUL(PSL_DMUL(dx, dx), w);
+            F.term[128 + F.lane] = PSL_DMUL(PSL_DMUL(dx, dy), w);
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (int t = 0; t < cnt; ++t) { Ixx = PSL_DADD(Ixx, F.term[t]); Iyy = PSL_DADD(Iyy, F.term[64 + t]); Ixy = PSL_DSUB(Ixy, F.term[128 + t]); }
+        __builtin_amdgcn_wave_barrier();
+    }
+    const double dI = PSL_DSUB(Ixx, Iyy);
+    const double lambda = PSL_DMUL(0.5, PSL_DSUB(PSL_DADD(Ixx, Iyy), __dsqrt_rn(PSL_DADD(PSL_DMUL(dI, dI), PSL_DMUL(PSL_DMUL(4.0, Ixy), Ixy)))));
+    double theta = (fabs(Ixx) > fabs(Iyy)) ? (double)psl_fast_atan2((float)PSL_DSUB(lambda, Ixx), (float)Ixy)
+                                           : (double)psl_fast_atan2((float)Ixy, (float)PSL_DSUB(lambda, Iyy));
+    theta = PSL_DMUL(theta, PSL_DEG2RAD);
+    if (fabs(psl_angle_diff_signed(theta, reg_angle)) > prec) theta = PSL_DADD(theta, PSL_PI);
+    const double dx = cos(theta), dy = sin(theta);
+    double l_min = 0, l_max = 0, w_min = 0, w_max = 0;  // order-independent: max(0, max l), min(0, min l)
+    for (int j = F.lane; j < reg_size; j += 64) {
+        const uint32_t rp = lsdw_reg(F, j, reg_size);
+        const double rdx = PSL_DSUB((double)(int)(rp & 0xffff), x), rdy = PSL_DSUB((double)(int)(rp >> 16), y);
+        const double l = PSL_DADD(PSL_DMUL(rdx, dx), PSL_DMUL(rdy, dy));
+        const double w = PSL_DADD(PSL_DMUL(-rdx, dy), PSL_DMUL(rdy, dx));
+        l_max = l > l_max ? l : l_max; l_min = l < l_min ? l : l_min;
+        w_max = w > w_max ? w : w_max; w_min = w < w_min ? w : w_min;
+    }
+    l_max = lsdw_wave_max(l_max); l_min = lsdw_wave_min(l_min);
+    w_max = lsdw_wave_max(w_max); w_min = lsdw_wave_min(w_min);
+    rec->x1 = PSL_DADD(x, PSL_DMUL(l_min, dx)); rec->y1 = PSL_DADD(y, PSL_DMUL(l_min, dy));
+    rec->x2 = PSL_DADD(x, PSL_DMUL(l_max, dx)); rec->y2 = PSL_DADD(y, PSL_DMUL(l_max, dy));
+    rec->width = PSL_DSUB(w_max, w_min);
+    if (rec->width < 1.0) rec->width = 1.0;
+}
+
+__device__ int lsdw_refine(const LsdW& F, int reg_size, double reg_angle, double prec, LsdRect* rec, double density_th) {
+    double density = psl_lsd_density(reg_size, *rec);
+    if (density >= density_th) return reg_size;
+    const uint32_t r0 = lsdw_reg(F, 0, reg_size);
+    const int x0 = (int)(r0 & 0xffff), y0 = (int)(r0 >> 16);
+    const double xc = (double)x0, yc = (double)y0;
+    const double ang_c = PSL_DMUL((double)F.ang[x0 + y0 * F.W], PSL_DEG2RAD);
+    double sum = 0, s_sum = 0;
+    int n = 0;
+    for (int base = 0; base < reg_size; base += 64) {
+        const int j = base + F.lane, cnt = min(64, reg_size - base);
+        double ang_d = 0;
+        bool in = false;
+        if (j < reg_size) {
+            const uint32_t rp = lsdw_reg(F, j, reg_size);
+            const int px = (int)(rp & 0xffff), py = (int)(rp >> 16), a = px + py * F.W;
+            atomicAnd(&F.used[a >> 5], ~(1u << (a & 31)));
+            if (__dsqrt_rn(psl_dist_sq(xc, yc, (double)px, (double)py)) < rec->width) {
+                in = true;
+                ang_d = psl_angle_diff_signed(PSL_DMUL((double)F.ang[a], PSL_DEG2RAD), ang_c);
+            }
+        }
+        F.term[F.lane] = ang_d;
+        const unsigned long long m = __ballot(in);
+        __builtin_amdgcn_wave_barrier();
+        for (int t = 0; t < cnt; ++t)
+            if ((m >> t) & 1ull) { const double d = F.term[t]; sum = PSL_DADD(sum, d); s_sum = PSL_DADD(s_sum, PSL_DMUL(d, d)); ++n; }
+        __builtin_amdgcn_wave_barrier();
+    }
+    const double mean_angle = sum / (double)n;
+    const double tau = PSL_DMUL(2.0, __dsqrt_rn(PSL_DADD(PSL_DSUB(s_sum, PSL_DMUL(PSL_DMUL(2.0, mean_angle), sum)) / (double)n, PSL_DMUL(mean_angle, mean_angle))));
+    reg_size = lsdw_region_grow(F, x0, y0, &reg_angle, tau);
+    if (reg_size < 2) return 0;
+    lsdw_region2rect(F, reg_size, reg_angle, prec, rec);
+    density = psl_lsd_density(reg_size, *rec);
+    if (density >= density_th) return reg_size;
+    // reduce_region_radius: rare; the swap-with-last compaction defines the later summation order, so it
+    // runs as written (uniform scalar code, lane 0 stores; the queue is re-mirrored into the ring afterwards)
+    const double d1 = psl_dist_sq(xc, yc, rec->x1, rec->y1), d2 = psl_dist_sq(xc, yc, rec->x2, rec->y2);
+    double radSq = d1 > d2 ? d1 : d2;
+    for (int j = F.lane; j < reg_size; j += 64) F.reg[j] = lsdw_reg(F, j, reg_size);  // make HBM copy authoritative
+    __builtin_amdgcn_wave_barrier();
+    while (density < density_th) {
+        radSq = PSL_DMUL(radSq, 0.75 * 0.75);
+        for (int i = 0; i < reg_size; ++i) {
+            const uint32_t rp = F.reg[i];
+            const int px = (int)(rp & 0xffff), py = (int)(rp >> 16);
+            if (psl_dist_sq(xc, yc, (double)px, (double)py) > radSq) {
+                const int a = px + py * F.W;
+                const uint32_t last = F.reg[reg_size - 1];
+                if (F.lane == 0) { F.used[a >> 5] &= ~(1u << (a & 31)); F.reg[i] = last; F.reg[reg_size - 1] = rp; }
+                __builtin_amdgcn_wave_barrier();
+                --reg_size;
+                --i;
+            }
+        }
+        if (reg_size < 2) return 0;
+        for (int j = F.lane; j < min(reg_size, PSL_LSD_RING); j += 64) {  // ring must mirror the last RING entries
+            const int idx = reg_size - 1 - j;
+            F.ring[idx & (PSL_LSD_RING - 1)] = F.reg[idx];
+        }
+        __builtin_amdgcn_wave_barrier();
+        lsdw_region2rect(F, reg_size, reg_angle, prec, rec);
+        density = psl_lsd_density(reg_size, *rec);
+    }
+    return reg_size;
+}
+
+__global__ __launch_bounds__(64) void k_lsd_grow2(LineParams P, const float* __restrict__ angdeg, const double* __restrict__ modgrad,
+                                                   const float4* __restrict__ trig, uint32_t* __restrict__ reg, float* __restrict__ seg,
+                                                   int* __restrict__ nseg) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];  // used bitmap
+    __shared__ uint32_t s_ring[PSL_LSD_RING];
+    __shared__ double s_term[3 * 64];
+    const int frame = blockIdx.x, lane = threadIdx.x;
+    const size_t npx = (size_t)P.W * P.H;
+    const int words = (int)((npx + 31) >> 5);
+    LsdW F;
+    F.W = P.W; F.H = P.H; F.lane = lane;
+    F.ang = angdeg + frame * npx; F.mod = modgrad + frame * npx; F.trig = trig + frame * npx; F.reg = reg + frame * npx;
+    F.used = s_dyn; F.ring = s_ring; F.term = s_term;
+    for (int i = lane; i < words; i += 64) F.used[i] = 0;
+    __builtin_amdgcn_wave_barrier();
+    float* out = seg + (size_t)frame * P.maxseg * 4;
+    int count = 0;
+    const int scan_end = (P.H - 1) * P.W;  // rows 0 .. H-2
+    for (int base = 0; base < scan_end; base += 256) {
+        float a4[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const int ad = base + q * 64 + lane; a4[q] = ad < scan_end ? F.ang[ad] : PSL_LSD_NOTDEF; }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int ad = base + q * 64 + lane;
+            unsigned long long mask = __ballot(a4[q] != PSL_LSD_NOTDEF);  // column W-1 and row H-1 are NOTDEF by construction
+            while (mask) {
+                const int s = __ffsll((long long)mask) - 1;
+                mask &= mask - 1;
+                const int adx = base + q * 64 + s;
+                if (lsdw_used(F, adx)) continue;
+                const int y = adx / P.W, x = adx - y * P.W;
+                double reg_angle;
+                int reg_size = lsdw_region_grow(F, x, y, &reg_angle, P.prec);
+                if (reg_size < P.min_reg_size) continue;
+                LsdRect rec;
+                lsdw_region2rect(F, reg_size, reg_angle, P.prec, &rec);
+                if (!lsdw_refine(F, reg_size, reg_angle, P.prec, &rec, 0.7)) continue;
+                if (count < P.maxseg && lane == 0) {
+                    float e[4] = {(float)(PSL_DADD(rec.x1, 0.5) / 0.8), (float)(PSL_DADD(rec.y1, 0.5) / 0.8),
+                                  (float)(PSL_DADD(rec.x2, 0.5) / 0.8), (float)(PSL_DADD(rec.y2, 0.5) / 0.8)};
+                    if (e[0] < 0) e[0] = 0;
+                    if (e[0] >= P.w) e[0] = (float)P.w - 1.0f;
+                    if (e[2] < 0) e[2] = 0;
+                    if (e[2] >= P.w) e[2] = (float)P.w - 1.0f;
+                    if (e[1] < 0) e[1] = 0;
+                    if (e[1] >= P.h) e[1] = (float)P.h - 1.0f;
+                    if (e[3] < 0) e[3] = 0;
+                    if (e[3] >= P.h) e[3] = (float)P.h - 1.0f;
+                    out[4 * count] = e[0]; out[4 * count + 1] = e[1]; out[4 * count + 2] = e[2]; out[4 * count + 3] = e[3];
+                }
+                ++count;
+            }
+            (void)ad;
+        }
+    }
+    if (lane == 0) nseg[frame] = count < P.maxseg ? count : P.maxseg;
 }
 
 #endif

@@ -1,6 +1,7 @@
 // libpslfe: line extractor object (== ORB_SLAM2::LINEextractor) over the HIP kernels. Product code.
 // Reference: add_src/LineExtractor.cpp:6-25, 325-366; add_inc/LineExtractor.h:160-255.
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -26,6 +27,7 @@ struct pslfe_line {
     double* d_scaled = nullptr;
     float* d_angdeg = nullptr;
     double* d_modgrad = nullptr;
+    float4* d_trig = nullptr;
     uint8_t* d_used = nullptr;
     uint32_t* d_reg = nullptr;
     float* d_seg = nullptr;
@@ -53,6 +55,7 @@ struct pslfe_line {
         hipFree(d_dx); hipFree(d_dy); hipFree(d_rawfans); hipFree(d_fans); hipFree(d_nfans); hipFree(d_tmplines);
         d_kls = nullptr; d_ldesc = nullptr; d_fdesc = nullptr; d_lineEq = nullptr; d_nkl = nullptr; d_status = nullptr; d_lbdblur = nullptr;
         d_dx = nullptr; d_dy = nullptr; d_rawfans = nullptr; d_fans = nullptr; d_nfans = nullptr; d_tmplines = nullptr;
+        hipFree(d_trig); d_trig = nullptr;
         hipFree(d_in); hipFree(d_scaled); hipFree(d_angdeg); hipFree(d_modgrad); hipFree(d_used); hipFree(d_reg);
         hipFree(d_seg); hipFree(d_nseg);
         d_in = nullptr; d_scaled = nullptr; d_angdeg = nullptr; d_modgrad = nullptr; d_used = nullptr; d_reg = nullptr;
@@ -109,6 +112,7 @@ struct pslfe_line {
         PSL_HIP(hipMalloc((void**)&d_scaled, npx * F * sizeof(double)));
         PSL_HIP(hipMalloc((void**)&d_angdeg, npx * F * sizeof(float)));
         PSL_HIP(hipMalloc((void**)&d_modgrad, npx * F * sizeof(double)));
+        PSL_HIP(hipMalloc((void**)&d_trig, npx * F * sizeof(float4)));
         PSL_HIP(hipMalloc((void**)&d_used, npx * F));
         PSL_HIP(hipMalloc((void**)&d_reg, npx * F * sizeof(uint32_t)));
         PSL_HIP(hipMalloc((void**)&d_seg, (size_t)Q.maxseg * 4 * sizeof(float) * F));
@@ -161,12 +165,18 @@ struct pslfe_line {
         }
         {
             PSL_STAGE_BEGIN(ctx, "line.lsd_grad");
-            k_lsd_grad<<<grid, 256, 0, st>>>(P, d_scaled, d_angdeg, d_modgrad);
+            k_lsd_grad<<<grid, 256, 0, st>>>(P, d_scaled, d_angdeg, d_modgrad, d_trig);
             PSL_STAGE_END(ctx, "line.lsd_grad");
         }
         {
             PSL_STAGE_BEGIN(ctx, "line.lsd_grow");
-            k_lsd_grow<<<F, 64, 0, st>>>(P, d_angdeg, d_modgrad, d_used, d_reg, d_seg, d_nseg);
+            const size_t lds = (((size_t)P.W * P.H + 31) / 32) * sizeof(uint32_t);
+            if (lds <= 140 * 1024 && !getenv("PSLFE_LSD_SERIAL")) {
+                if (lds > 48 * 1024) PSL_HIP(hipFuncSetAttribute((const void*)k_lsd_grow2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                k_lsd_grow2<<<F, 64, lds, st>>>(P, d_angdeg, d_modgrad, d_trig, d_reg, d_seg, d_nseg);
+            } else {
+                k_lsd_grow<<<F, 64, 0, st>>>(P, d_angdeg, d_modgrad, d_used, d_reg, d_seg, d_nseg);
+            }
             PSL_STAGE_END(ctx, "line.lsd_grow");
         }
         PSL_HIP(hipGetLastError());
