@@ -50,12 +50,22 @@ STAGE_BYTES_PER_FRAME = {
     "orb.describe": 512 * NFEATURES + 60 * NFEATURES,
     "match.grid": 2 * 60 * NFEATURES,
     "match.window": MATCH_BYTES_PER_FRAME,
+    # line path, SURVEY.md §8(d) "Lines @640x480" = 17 040 800 B/frame split over the kernels that move them
+    "line.lsd_scale": WH + 8 * 196608,                 # gray read + f64 working image write
+    "line.lsd_grad": 8 * 196608 + 2 * 8 * 196608,      # working image read + angle & modgrad write
+    "line.lsd_grow": 2 * 8 * 196608 + 2 * 8 * 196608 + 393216,  # angle & modgrad read + coordinate list w+r + used map
+    "line.merge": 2 * 16 * 500,
+    "line.lbd_pre": WH + WH + 4 * WH,                  # gray read, blur write, Sobel dx,dy s16 write
+    "line.lbd": 5040000 + 20000,                       # LSR gathers + outputs
+    "line.pair": 2 * 16 * 200,
+    "line.match": 12800,
 }
+LINE_BYTES_PER_FRAME = 17040800 + 12800
 
 
-def synth_batch(batch, seed, n_distinct=16):
+def synth_batch(batch, seed, n_distinct=16, style="desk"):
     import synth_frames as sf
-    sc = sf.Scene(W, H, "desk", seed)
+    sc = sf.Scene(W, H, style, seed)
     base = np.stack([sc.gray(t) for t in range(min(n_distinct, batch))], 0)
     reps = (batch + len(base) - 1) // len(base)
     # forward then backward in time so consecutive frames always differ by one drift step
@@ -63,7 +73,7 @@ def synth_batch(batch, seed, n_distinct=16):
     return np.ascontiguousarray(np.concatenate([seq] * reps, 0)[:batch])
 
 
-def cpu_baseline(sample_frames):
+def cpu_baseline(sample_frames, lines=False):
     """Oracle (CPU restatement) timed single-threaded on the same workload: extract + match."""
     import ctypes as C
     import oracle_lib
@@ -91,13 +101,23 @@ def cpu_baseline(sample_frames):
             q["min_level"], q["max_level"] = prev[0]["octave"] - 1, prev[0]["octave"] + 1
             q["angle"], q["blocks"] = prev[0]["angle"], 1
             oracle_lib.search_by_projection_last(kps, desc, None, (0.0, 0.0, float(W), float(H)), q, prev[1], None, True)
-        prev = (kps, desc)
+        if lines:
+            kls, ldesc, _ = oracle_lib.line_extract(img, 200)
+            L4 = np.stack([kls[k] for k in ("startPointX", "startPointY", "endPointX", "endPointY")], 1).astype(np.float32) if len(kls) else np.zeros((0, 4), np.float32)
+            oracle_lib.lil_pair(L4, 20.0, np.float32(np.pi / 4), W, H)
+            if prev is not None and len(prev) > 2:
+                oracle_lib.line_match_nnr(prev[2], ldesc, 0.9)
+            prev = (kps, desc, ldesc)
+        else:
+            prev = (kps, desc)
         n += 1
         if time.perf_counter() - t0 > 25.0:
             break
     dt = time.perf_counter() - t0
+    what = ("ORB 1000 + LSD/merge/LBD 200 + LIL pairing extract, SearchByProjection(cur,last) + matchNNR" if lines
+            else "ORB 1000 extract + SearchByProjection(cur,last)")
     return {"value": round(n / dt, 2), "unit": "frames/s", "cores": 1, "kind": "port",
-            "sample": f"{n} frames 640x480 desk-like synthetic stream, ORB 1000 extract + SearchByProjection(cur,last), "
+            "sample": f"{n} frames 640x480 synthetic stream, {what}, "
                       f"oracle/ built -O3 -march=native, 1 thread, {dt:.1f} s on {os.cpu_count()} host cores available"}
 
 
@@ -106,7 +126,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=256, help="frames per step per GPU")
+    ap.add_argument("--batch", type=int, default=0, help="frames per step per GPU (default 256; 1024 for --workload lines)")
+    ap.add_argument("--workload", choices=["orb", "lines"], default="orb",
+                    help="orb = BASELINE configs[1] (ORB extract+match); lines = configs[2] (ORB + LSD/LBD + pairing, extract+match)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -126,8 +148,9 @@ def main():
     from importlib import import_module
     multigpu = import_module("psl_slam_amd.multigpu")
     P.build()
-    B = args.batch
-    frames_h = synth_batch(B, P_seed(rank))
+    LINES = args.workload == "lines"
+    B = args.batch or (1024 if LINES else 256)
+    frames_h = synth_batch(B, P_seed(rank), style="struct" if LINES else "desk")
     frames_d = torch.from_numpy(frames_h).to(dev)
 
     # a real (non-null) torch stream: the library launches on it, so torch ops, RCCL and the HIP
@@ -149,6 +172,14 @@ def main():
     match = torch.full((B, cap), -1, dtype=torch.int32, device=dev)
     nmatches = torch.zeros((B,), dtype=torch.int32, device=dev)
     q_i32 = queries.view(torch.int32)
+
+    le = None
+    if LINES:
+        le = P.LINEextractor(1, 1.2, 200, 0.0, ctx=ctx, max_batch=B)
+        le.extract_batch_device(frames_d.data_ptr(), B, W, H, W, W * H)
+        _, _, _, _, klcap = le.results_device()
+        lmatch = torch.full((B, klcap), -1, dtype=torch.int32, device=dev)
+        lnm = torch.zeros((B,), dtype=torch.int32, device=dev)
 
     gather = None
 
@@ -174,6 +205,10 @@ def main():
         nq.copy_(torch.roll(counts, 1, 0))
         P.search_by_projection_last_device(grid, 0, B, queries.data_ptr(), qdesc.data_ptr(), nq.data_ptr(), cap, True,
                                            match.data_ptr(), nmatches.data_ptr())
+        if LINES:
+            le.extract_batch_device(frames_d.data_ptr(), B, W, H, W, W * H)   # LSD -> merge -> top-200 -> LBD -> line equations
+            le.pair_batch_device(20.0, float(np.float32(np.pi / 4)))          # CPartiallyRecoverConnectivity (src/Frame.cc:505)
+            le.match_batch_device(1, 0.9, lmatch.data_ptr(), lnm.data_ptr())  # lmatcher.match(last, cur, 0.9) (src/Tracking.cc:901)
         if gather is not None:
             gather.submit([counts, kps, desc, match, nmatches])
         return counts
@@ -209,7 +244,8 @@ def main():
         dt = float(t.item())
     ctx.profile(False)
 
-    stage_names = ["orb.pyramid", "orb.fast", "orb.octree", "orb.blur", "orb.describe", "match.grid", "match.window"]
+    stage_names = ["orb.pyramid", "orb.fast", "orb.octree", "orb.blur", "orb.describe", "match.grid", "match.window",
+                   "line.lsd_scale", "line.lsd_grad", "line.lsd_grow", "line.merge", "line.lbd_pre", "line.lbd", "line.pair", "line.match"]
     stages = {}
     for s in stage_names:
         ms, n = ctx.stage_time(s)
@@ -224,24 +260,30 @@ def main():
         dom_bytes = STAGE_BYTES_PER_FRAME[dom] * B
         dom_s = stages[dom]["ms_per_launch"] * 1e-3
         achieved = dom_bytes / dom_s / 1e9
+        per_frame = ORB_BYTES_PER_FRAME + MATCH_BYTES_PER_FRAME + (LINE_BYTES_PER_FRAME if LINES else 0)
         out = {
-            "metric": "frames/sec ORB extract+match, 640x480", "value": round(fps, 1), "unit": "frames/s",
+            "metric": "frames/sec ORB+line extract+match, 640x480" if LINES else "frames/sec ORB extract+match, 640x480",
+            "value": round(fps, 1), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "configs[1]: 640x480 synthetic RGB-D stream (desk-like), ORB 1000/1.2/8 FAST 20/7 "
-                                   "extract + SearchByProjection(cur,last) match, frames resident in HBM",
+            "config": {"workload": ("configs[2]: 640x480 synthetic structure-notexture-like stream, ORB 1000/1.2/8 FAST 20/7 + LSD/merge/LBD 200 lines "
+                                    "+ LIL pairing extract, SearchByProjection(cur,last) + LSDmatcher::match, frames resident in HBM") if LINES else
+                                   ("configs[1]: 640x480 synthetic RGB-D stream (desk-like), ORB 1000/1.2/8 FAST 20/7 "
+                                    "extract + SearchByProjection(cur,last) match, frames resident in HBM"),
                        "frames_per_step_per_gpu": B, "mean_keypoints": round(mean_kp, 1), "mean_matches": round(mean_matches, 1),
                        "multi_gpu": "independent stream per rank, RCCL all-gather of result records" if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
                          "algorithmic_bytes_per_launch": dom_bytes, "ms_per_launch": round(stages[dom]["ms_per_launch"], 4)},
-            "pipeline_roofline": {"bytes_per_frame": ORB_BYTES_PER_FRAME + MATCH_BYTES_PER_FRAME,
-                                  "achieved_GBs": round(fps / world * (ORB_BYTES_PER_FRAME + MATCH_BYTES_PER_FRAME) / 1e9, 2),
-                                  "frac_of_8TBs": round(fps / world * (ORB_BYTES_PER_FRAME + MATCH_BYTES_PER_FRAME) / 1e9 / HBM_PEAK_GBS, 5)},
+            "pipeline_roofline": {"bytes_per_frame": per_frame,
+                                  "achieved_GBs": round(fps / world * per_frame / 1e9, 2),
+                                  "frac_of_8TBs": round(fps / world * per_frame / 1e9 / HBM_PEAK_GBS, 5)},
             "stages_ms_per_launch": {k: round(v["ms_per_launch"], 4) for k, v in stages.items()},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(frames_h[:64])
+            out["cpu_baseline"] = cpu_baseline(frames_h[:64], lines=LINES)
+        if LINES:
+            out["config"]["mean_line_matches"] = round(float(lnm.float().mean().item()), 1)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

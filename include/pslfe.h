@@ -202,6 +202,12 @@ int pslfe_lil_pair(pslfe_line* line, const float* lines, int nlines, float radiu
 int pslfe_line_pair_batch_device(pslfe_line* line, float radius, float fanThr);
 int pslfe_line_fans_fetch(pslfe_line* line, int frame, float* fans, int cap, int* nfans);
 
+/* == lmatcher.match(mLastFrame.mLdesc, mCurrentFrame.mLdesc, nnr, matches_12) of src/Tracking.cc:901
+ *    (LSDmatcher::match -> matchNNR, add_src/LSDmatcher.cpp:354-413) for every frame f of the last
+ *    extracted batch against frame (f - shift) mod nframes, HBM resident, asynchronous.
+ *    d_matches12: [nframes][kl_cap] int32, row f indexed by the LAST frame's line; d_nmatches: [nframes]. */
+int pslfe_line_match_batch_device(pslfe_line* line, int shift, float nnr, int32_t* d_matches12, int32_t* d_nmatches);
+
 /* ---- descriptor matching --------------------------------------------------------------------- */
 /* == cv::BFMatcher(NORM_HAMMING).knnMatch(q, t, k=2) as used by LSDmatcher::matchNNR
  *    add_src/LSDmatcher.cpp:354-376 and FrameBFMatch :492-516.  256-bit descriptors, row-major

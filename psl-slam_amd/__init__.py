@@ -451,7 +451,7 @@ def _line_call(self, image, mask=None):
         return np.zeros(0, KEYLINE_DTYPE), np.zeros((0, 32), np.uint8), np.zeros((0, 3))
     assert image.dtype == np.uint8 and image.ndim == 2
     h, w = image.shape
-    cap = 2048
+    cap = 1024
     kls = np.zeros(cap, KEYLINE_DTYPE)
     desc = np.zeros((cap, 32), np.uint8)
     eq = np.zeros((cap, 3), np.float64)
@@ -466,7 +466,7 @@ def _line_extract_batch_device(self, d_ptr, nframes, w, h, stride, frame_stride)
                                                  C.c_size_t(frame_stride)), "pslfe_line_extract_batch_device")
 
 
-def _line_fetch(self, frame, cap=2048):
+def _line_fetch(self, frame, cap=1024):
     kls = np.zeros(cap, KEYLINE_DTYPE)
     desc = np.zeros((cap, 32), np.uint8)
     eq = np.zeros((cap, 3), np.float64)
@@ -482,7 +482,7 @@ def _line_results_device(self):
     return k.value, d.value, e.value, c.value, cap.value
 
 
-def _line_optimize_and_merge(self, segments, w, h, cap=2048):
+def _line_optimize_and_merge(self, segments, w, h, cap=1024):
     seg = np.ascontiguousarray(segments, np.float32).reshape(-1, 4)
     kls = np.zeros(cap, KEYLINE_DTYPE)
     n = C.c_int()
@@ -529,6 +529,12 @@ def _line_fans_fetch(self, frame, cap=4096):
     return fans[:k.value].copy()
 
 
+def _line_match_batch_device(self, shift, nnr, d_matches12, d_nmatches):
+    _check(lib().pslfe_line_match_batch_device(self._h, C.c_int(shift), C.c_float(nnr), C.c_void_p(d_matches12), C.c_void_p(d_nmatches)),
+           "pslfe_line_match_batch_device")
+
+
+LINEextractor.match_batch_device = _line_match_batch_device
 LINEextractor.__call__ = _line_call
 LINEextractor.extract_batch_device = _line_extract_batch_device
 LINEextractor.fetch = _line_fetch

@@ -623,4 +623,46 @@ __global__ __launch_bounds__(256) void k_lil_pair(const float* __restrict__ line
     if (tid == 0) nfans[frame] = kept < fan_cap ? kept : fan_cap;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// LSDmatcher::matchNNR (add_src/LSDmatcher.cpp:354-376) for every frame of a batch against the frame
+// `shift` positions earlier (cyclic), i.e. lmatcher.match(mLastFrame.mLdesc, mCurrentFrame.mLdesc, nnr)
+// of src/Tracking.cc:901 for a whole stream at once.  One wave per query row; kNN-2 by Hamming
+// distance with "lower train index first"; accept d0 < d1 * nnr (float compare).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_line_match_batch(const uint8_t* __restrict__ desc, const int* __restrict__ counts, int cap, int nframes,
+                                                           int shift, float nnr, int* __restrict__ matches12, int* __restrict__ nmatches) {
+    const int cur = blockIdx.x, lane = threadIdx.x & 63;
+    const int last = ((cur - shift) % nframes + nframes) % nframes;
+    const int n1 = min(counts[last], cap), n2 = min(counts[cur], cap);
+    const int qi = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (qi >= n1) return;
+    const uint32_t* Q = reinterpret_cast<const uint32_t*>(desc + ((size_t)last * cap + qi) * 32);
+    const uint32_t* T = reinterpret_cast<const uint32_t*>(desc + (size_t)cur * cap * 32);
+    uint32_t qd[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) qd[k] = Q[k];
+    uint32_t k1 = 0xffffffffu, k2 = 0xffffffffu;
+    for (int j = lane; j < n2; j += 64) {
+        int d = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) d += __popc(qd[k] ^ T[(size_t)j * 8 + k]);
+        const uint32_t key = ((uint32_t)d << 20) | (uint32_t)j;
+        if (key < k1) { k2 = k1; k1 = key; } else if (key < k2) k2 = key;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const uint32_t o1 = __shfl_xor(k1, o), o2 = __shfl_xor(k2, o);
+        const uint32_t lo = min(k1, o1), hi = max(k1, o1);
+        k2 = min(hi, min(k2, o2));
+        k1 = lo;
+    }
+    if (lane == 0) {
+        int m = -1;
+        if (n2 >= 2 && (float)(k1 >> 20) < PSL_FMUL((float)(k2 >> 20), nnr)) m = (int)(k1 & 0xfffff);
+        matches12[(size_t)cur * cap + qi] = m;
+        if (m >= 0) atomicAdd(&nmatches[cur], 1);
+    }
+}
+
 #endif

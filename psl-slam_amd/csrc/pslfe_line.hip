@@ -71,7 +71,7 @@ struct pslfe_line {
         Q.W = (int)nearbyint(w * 0.8);
         Q.H = (int)nearbyint(h * 0.8);
         Q.maxseg = PSL_MERGE_NMAX;
-        Q.maxkl = 2048;
+        Q.maxkl = std::max(1024, nfeatures);
         Q.nfeatures = nfeatures;
         {   // getGaussianKernel(7, 0.75, CV_64F): sigma = SIGMA_SCALE / SCALE, ksize = 1 + 2*ceil(sigma*sqrt(2*3*ln 10))
             const double sigma = 0.6 / 0.8;
@@ -486,6 +486,28 @@ int pslfe_line_fans_fetch(pslfe_line* line, int frame, float* fans, int cap, int
         PSL_HIP(hipMemcpyAsync(fans, line->d_fans + (size_t)frame * PSL_FAN_CAP * 4, (size_t)k * 4 * sizeof(float), hipMemcpyDeviceToHost, st));
         PSL_HIP(hipStreamSynchronize(st));
     }
+    return PSLFE_OK;
+}
+
+
+// == lmatcher.match(mLastFrame.mLdesc, mCurrentFrame.mLdesc, nnr, matches_12) (src/Tracking.cc:901 ->
+//    LSDmatcher::match -> matchNNR, add_src/LSDmatcher.cpp:354-413) for every frame f of the last batch
+//    against frame (f - shift) mod nframes; HBM resident.  d_matches12: [nframes][cap] (row f indexed by the
+//    LAST frame's line, value = index into frame f's lines or -1), d_nmatches: [nframes].
+int pslfe_line_match_batch_device(pslfe_line* line, int shift, float nnr, int32_t* d_matches12, int32_t* d_nmatches) {
+    PSL_REQUIRE(line && d_matches12 && d_nmatches, PSLFE_E_INVALID, "pslfe_line_match_batch_device: NULL argument");
+    PSL_REQUIRE(line->last_nframes > 0, PSLFE_E_STATE, "pslfe_line_match_batch_device: no batch extracted yet");
+    PSL_HIP(hipSetDevice(line->ctx->device));
+    hipStream_t st = line->ctx->stream;
+    const int F = line->last_nframes, cap = line->P.maxkl;
+    PSL_HIP(hipMemsetAsync(d_nmatches, 0, (size_t)F * sizeof(int), st));
+    {
+        PSL_STAGE_BEGIN(line->ctx, "line.match");
+        const int qmax = std::min(cap, line->P.nfeatures);
+        k_line_match_batch<<<dim3(F, (qmax + 3) / 4), 256, 0, st>>>(line->d_ldesc, line->d_nkl, cap, F, shift, nnr, d_matches12, d_nmatches);
+        PSL_STAGE_END(line->ctx, "line.match");
+    }
+    PSL_HIP(hipGetLastError());
     return PSLFE_OK;
 }
 

@@ -195,7 +195,25 @@ def test_line_extractor_batch_and_pairing_device():
         fans = le.fans_fetch(f)
         ref = single.pair(lines, 20.0, np.float32(np.pi / 4), 640, 480)
         assert fans.tobytes() == ref.tobytes()
-    le.ctx.device_free(d_ptr)
+    # batched LSDmatcher::match(last, cur, 0.9) on the HBM-resident descriptors vs the oracle
+    import oracle_lib
+    import ctypes as C
+    cap = le.results_device()[4]
+    d_m, _ = le.ctx.device_array(np.full((3, cap), -7, np.int32))
+    d_n, _ = le.ctx.device_array(np.zeros(3, np.int32))
+    le.match_batch_device(1, 0.9, d_m, d_n)
+    le.ctx.synchronize()
+    m = np.zeros((3, cap), np.int32)
+    nm = np.zeros(3, np.int32)
+    P._check(P.lib().pslfe_device_download(le.ctx._h, P._ptr(m), C.c_void_p(d_m), C.c_size_t(m.nbytes)), "download")
+    P._check(P.lib().pslfe_device_download(le.ctx._h, P._ptr(nm), C.c_void_p(d_n), C.c_size_t(nm.nbytes)), "download")
+    descs = [le.fetch(f)[1] for f in range(3)]
+    for f in range(3):
+        rn, rm = oracle_lib.line_match_nnr(descs[(f - 1) % 3], descs[f], 0.9)
+        assert nm[f] == rn
+        np.testing.assert_array_equal(m[f, :len(rm)], rm)
+    for d in (d_ptr, d_m, d_n):
+        le.ctx.device_free(d)
 
 
 def test_line_extractor_empty_inputs():
