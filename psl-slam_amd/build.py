@@ -38,7 +38,7 @@ def build(force=False, verbose=True):
         return OUT
     cmd = [HIPCC] + FLAGS + sources() + ["-o", OUT]
     if verbose:
-        print(" ".join(cmd), flush=True)
+        print(" ".join(cmd), file=sys.stderr, flush=True)
     subprocess.run(cmd, check=True)
     return OUT
 

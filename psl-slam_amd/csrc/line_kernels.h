@@ -92,6 +92,91 @@ __global__ __launch_bounds__(256) void k_lsd_scale(LineParams P, const uint8_t* 
     scaled[(size_t)frame * P.W * P.H + (size_t)dy * P.W + dx] = PSL_DADD(PSL_DMUL(h0, b0), PSL_DMUL(h1, b1));
 }
 
+// Tiled form of k_lsd_scale: a 64 x 16 tile of the working image needs <= 82 x 22 blurred samples,
+// i.e. <= 88 x 28 input pixels; they are staged once in LDS (reflect-101 applied while loading), row
+// sums and column sums are formed once per sample in the same operation order as above, and the
+// bilinear step reads the blurred tile.  ~9x fewer f64 operations than the per-pixel form.
+#define PSL_LS_IC 88
+#define PSL_LS_IR 28
+#define PSL_LS_BC 82
+#define PSL_LS_BR 22
+__device__ __forceinline__ void psl_lsd_src(int d, int ssize, int* s, float* f, bool clamp_coef) {
+    const double sc = 1. / 0.8;
+    float ff = (float)((d + 0.5) * sc - 0.5);
+    int ss = (int)__builtin_floorf(ff);
+    ff -= ss;
+    if (clamp_coef) {
+        if (ss < 0) { ff = 0; ss = 0; }
+        if (ss >= ssize - 1) { ff = 0; ss = ssize - 1; }
+    }
+    *s = ss; *f = ff;
+}
+
+__global__ __launch_bounds__(256) void k_lsd_scale_tiled(LineParams P, const uint8_t* __restrict__ gray, int stride, size_t fstride,
+                                                          double* __restrict__ scaled) {
+    __shared__ uint8_t s_in[PSL_LS_IR * PSL_LS_IC];
+    __shared__ double s_rs[PSL_LS_IR * PSL_LS_BC];
+    __shared__ double s_bl[PSL_LS_BR * PSL_LS_BC];
+    const int frame = blockIdx.z, tid = threadIdx.x;
+    const int dx0 = blockIdx.x * 64, dy0 = blockIdx.y * 16;
+    const uint8_t* img = gray + (size_t)frame * fstride;
+    // blurred sample range of this tile
+    int s, bx0, bx1, by0, by1;
+    float f;
+    psl_lsd_src(dx0, P.w, &bx0, &f, true);
+    psl_lsd_src(min(dx0 + 63, P.W - 1), P.w, &s, &f, true);
+    bx1 = min(s + 1, P.w - 1);
+    psl_lsd_src(dy0, P.h, &s, &f, false);
+    by0 = min(max(s, 0), P.h - 1);
+    psl_lsd_src(min(dy0 + 15, P.H - 1), P.h, &s, &f, false);
+    by1 = min(max(s + 1, 0), P.h - 1);
+    const int nbc = bx1 - bx0 + 1, nbr = by1 - by0 + 1;  // <= 82, <= 22 for scale 0.8
+    const int nic = nbc + 6, nir = nbr + 6;
+    for (int k = tid; k < nir * nic; k += 256) {
+        const int r = k / nic, c = k - r * nic;
+        s_in[r * PSL_LS_IC + c] = img[(size_t)psl_reflect101i(by0 - 3 + r, P.h) * stride + psl_reflect101i(bx0 - 3 + c, P.w)];
+    }
+    __syncthreads();
+    for (int k = tid; k < nir * nbc; k += 256) {  // RowFilter: s = k0*S0; s += k1*S1; ...
+        const int r = k / nbc, c = k - r * nbc;
+        const uint8_t* in = &s_in[r * PSL_LS_IC + c];
+        double acc = PSL_DMUL(P.gk[0], (double)in[0]);
+#pragma unroll
+        for (int j = 1; j < 7; ++j) acc = PSL_DADD(acc, PSL_DMUL(P.gk[j], (double)in[j]));
+        s_rs[r * PSL_LS_BC + c] = acc;
+    }
+    __syncthreads();
+    for (int k = tid; k < nbr * nbc; k += 256) {  // SymmColumnFilter: centre, then (S[k] + S[-k]) * ky[k]
+        const int r = k / nbc, c = k - r * nbc;
+        const double* rs = &s_rs[(r + 3) * PSL_LS_BC + c];
+        double acc = PSL_DMUL(P.gk[3], rs[0]);
+#pragma unroll
+        for (int j = 1; j <= 3; ++j) acc = PSL_DADD(acc, PSL_DMUL(P.gk[3 + j], PSL_DADD(rs[j * PSL_LS_BC], rs[-j * PSL_LS_BC])));
+        s_bl[r * PSL_LS_BC + c] = acc;
+    }
+    __syncthreads();
+    for (int k = tid; k < 64 * 16; k += 256) {
+        const int dx = dx0 + (k & 63), dy = dy0 + (k >> 6);
+        if (dx >= P.W || dy >= P.H) continue;
+        int sx, sy;
+        float fx, fy;
+        psl_lsd_src(dx, P.w, &sx, &fx, true);
+        psl_lsd_src(dy, P.h, &sy, &fy, false);
+        const double a0 = (double)(1.f - fx), a1 = (double)fx, b0 = (double)(1.f - fy), b1 = (double)fy;
+        const int sy0 = min(max(sy, 0), P.h - 1) - by0, sy1 = min(max(sy + 1, 0), P.h - 1) - by0;
+        const int cx = sx - bx0;
+        double h0, h1;
+        if (sx + 1 < P.w) {
+            h0 = PSL_DADD(PSL_DMUL(s_bl[sy0 * PSL_LS_BC + cx], a0), PSL_DMUL(s_bl[sy0 * PSL_LS_BC + cx + 1], a1));
+            h1 = PSL_DADD(PSL_DMUL(s_bl[sy1 * PSL_LS_BC + cx], a0), PSL_DMUL(s_bl[sy1 * PSL_LS_BC + cx + 1], a1));
+        } else {
+            h0 = s_bl[sy0 * PSL_LS_BC + cx];
+            h1 = s_bl[sy1 * PSL_LS_BC + cx];
+        }
+        scaled[(size_t)frame * P.W * P.H + (size_t)dy * P.W + dx] = PSL_DADD(PSL_DMUL(h0, b0), PSL_DMUL(h1, b1));
+    }
+}
+
 // LSD step 2 (ll_angle): 2x2 gradient, norm (f64, correctly rounded sqrt), level-line angle by the
 // f32 fastAtan2 polynomial.  The angle is stored as f32 degrees (the reference's double is exactly
 // double(deg) * DEG_TO_RADS, recomputed where it is used); NOTDEF = -1024.

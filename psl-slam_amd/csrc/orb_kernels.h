@@ -137,6 +137,8 @@ __global__ __launch_bounds__(256) void k_fast_cells(OrbParams P, FrameSrc S, int
     __shared__ uint8_t s_score[(PSL_MAXCELL + 2) * PSL_FAST_SP];
     __shared__ int s_cnt[2][64];  // survivors per (pass, wave) at iniTh / minTh
     __shared__ int s_off[2][65];
+    __shared__ uint16_t s_list[PSL_MAXCELL * PSL_MAXCELL];  // pixels that pass the quick corner test
+    __shared__ int s_nlist;
 
     const int cell = blockIdx.x, frame = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -168,19 +170,43 @@ __global__ __launch_bounds__(256) void k_fast_cells(OrbParams P, FrameSrc S, int
     }
     for (int k = tid; k < (ih + 2) * PSL_FAST_SP; k += 256) s_score[k] = 0;
     if (tid < 128) (&s_cnt[0][0])[tid] = 0;
+    if (tid == 0) s_nlist = 0;
     __syncthreads();
 
     const int npix = iw * ih;
     const int npass = (npix + 255) >> 8;
     const int minTh = P.minTh, iniTh = P.iniTh;
+    // Quick reject (exact necessary condition): an arc of 9 contains one pixel of every opposite pair, so a
+    // pixel with S >= minTh has, for the 4 pairs (0,8) (2,10) (4,12) (6,14), one member > v+minTh in each
+    // pair or one member < v-minTh in each pair.  Survivors (a few % of the pixels) are compacted and
+    // only they pay for the full score.
     for (int p = 0; p < npass; ++p) {
         const int idx = p * 256 + tid;
+        bool pass = false;
         if (idx < npix) {
             const int y = idx / iw, x = idx - y * iw;
-            int s = psl_fast_score(&s_tile[(y + 3) * PSL_FAST_TP + x + 3], PSL_FAST_TP);
-            s = s < minTh ? 0 : (s > 255 ? 255 : s);
-            s_score[(y + 1) * PSL_FAST_SP + x + 1] = (uint8_t)s;
+            const uint8_t* c = &s_tile[(y + 3) * PSL_FAST_TP + x + 3];
+            const int hi = c[0] + minTh, lo = c[0] - minTh;
+            const int r0 = c[3 * PSL_FAST_TP], r8 = c[-3 * PSL_FAST_TP], r4 = c[3], r12 = c[-3];
+            const int r2 = c[2 * PSL_FAST_TP + 2], r10 = c[-2 * PSL_FAST_TP - 2], r6 = c[-2 * PSL_FAST_TP + 2], r14 = c[2 * PSL_FAST_TP - 2];
+            const bool b = ((r0 > hi) | (r8 > hi)) & ((r4 > hi) | (r12 > hi)) & ((r2 > hi) | (r10 > hi)) & ((r6 > hi) | (r14 > hi));
+            const bool d = ((r0 < lo) | (r8 < lo)) & ((r4 < lo) | (r12 < lo)) & ((r2 < lo) | (r10 < lo)) & ((r6 < lo) | (r14 < lo));
+            pass = b | d;
         }
+        const unsigned long long m = __ballot(pass);
+        int base = 0;
+        if (lane == 0 && m) base = atomicAdd(&s_nlist, __popcll(m));
+        base = __shfl(base, 0);
+        if (pass) s_list[base + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)idx;
+    }
+    __syncthreads();
+    const int nlist = s_nlist;
+    for (int i = tid; i < nlist; i += 256) {
+        const int idx = s_list[i];
+        const int y = idx / iw, x = idx - y * iw;
+        int s = psl_fast_score(&s_tile[(y + 3) * PSL_FAST_TP + x + 3], PSL_FAST_TP);
+        s = s < minTh ? 0 : (s > 255 ? 255 : s);
+        s_score[(y + 1) * PSL_FAST_SP + x + 1] = (uint8_t)s;
     }
     __syncthreads();
 
@@ -201,11 +227,8 @@ __global__ __launch_bounds__(256) void k_fast_cells(OrbParams P, FrameSrc S, int
         }
         const unsigned long long b_min = __ballot(f_min), b_ini = __ballot(f_ini);
         if (lane == 0) { s_cnt[0][p * 4 + wave] = __popcll(b_ini); s_cnt[1][p * 4 + wave] = __popcll(b_min); }
-        const unsigned long long below = (1ull << lane) - 1ull;
-        // remember the flag and the rank inside the wave (rank < 64 fits beside the flag later)
         keep_ini |= (uint32_t)f_ini << p;
         keep_min |= (uint32_t)f_min << p;
-        (void)below;
     }
     __syncthreads();
     if (wave == 0) {  // exclusive scan of the 64 (pass, wave) counts, both thresholds
@@ -477,7 +500,6 @@ __global__ __launch_bounds__(BS) void k_octree(OrbParams P, const int* __restric
 // ---------------------------------------------------------------------------------------------
 // GaussianBlur 7x7 sigma 2, BORDER_REFLECT_101, on every (un-padded) level: OpenCV 3.2 8-bit
 // path = integer kernel round(k*256), 32-bit row sums, (v + 2^15) >> 16 (Appendix A.4).
-// 64 x 16 output tile per workgroup, separable through LDS (row sums fit 16 bits: 255*257).
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ int psl_reflect101(int p, int n) {
     if (n == 1) return 0;
@@ -485,46 +507,75 @@ __device__ __forceinline__ int psl_reflect101(int p, int n) {
     return p;
 }
 
+// 64 x 64 output tile per workgroup: 70 x 72-byte input rows staged in LDS (dword loads when the
+// tile lies inside the image and the rows are 4-byte aligned, per-byte reflect-101 at the borders), row
+// sums as u16 (255*257 fits), then the column pass; every thread produces 4 adjacent pixels per step.
+#define PSL_BLUR_TH 64
 __global__ __launch_bounds__(256) void k_blur7(OrbParams P, FrameSrc S, uint8_t* __restrict__ blur, size_t blur_fstride) {
-    __shared__ uint8_t s_in[22][72];
-    __shared__ uint16_t s_row[22][64];
+    __shared__ __attribute__((aligned(16))) uint8_t s_in[(PSL_BLUR_TH + 6) * 72];
+    __shared__ __attribute__((aligned(16))) uint16_t s_row[(PSL_BLUR_TH + 6) * 64];
     const int tile = blockIdx.x, frame = blockIdx.y, tid = threadIdx.x;
     int level = 0;
     while (level + 1 < P.nlevels && tile >= P.lv[level + 1].tile_off) ++level;
     const OrbLevelP L = P.lv[level];
     const int t = tile - L.tile_off;
     const int ty = t / L.tiles_x, tx = t - ty * L.tiles_x;
-    const int x0 = tx * 64, y0 = ty * 16;
+    const int x0 = tx * 64, y0 = ty * PSL_BLUR_TH;
+    const int rows = min(PSL_BLUR_TH, L.h - y0) + 6;  // input rows y0-3 .. y0+rows-4
     int pitch;
     const uint8_t* img = psl_level_ptr(P, S, level, frame, &pitch);
-    for (int k = tid; k < 22 * 70; k += 256) {
-        const int yy = k / 70, xx = k - yy * 70;
-        const int gy = psl_reflect101(y0 + yy - 3, L.h), gx = psl_reflect101(x0 + xx - 3, L.w);
-        s_in[yy][xx] = img[(size_t)gy * pitch + gx];
+    // s_in[r][c] holds pixel (x0 - 4 + c, y0 - 3 + r), c in [0, 72)
+    const bool fast = x0 >= 4 && x0 + 68 <= L.w && ((reinterpret_cast<uintptr_t>(img) | (uintptr_t)pitch) & 3) == 0;
+    if (fast) {
+        for (int k = tid; k < rows * 18; k += 256) {
+            const int r = k / 18, c4 = k - r * 18;
+            const int gy = psl_reflect101(y0 + r - 3, L.h);
+            reinterpret_cast<uint32_t*>(s_in)[r * 18 + c4] = *reinterpret_cast<const uint32_t*>(img + (size_t)gy * pitch + x0 - 4 + c4 * 4);
+        }
+    } else {
+        for (int k = tid; k < rows * 72; k += 256) {
+            const int r = k / 72, c = k - r * 72;
+            const int gy = psl_reflect101(y0 + r - 3, L.h), gx = psl_reflect101(x0 - 4 + c, L.w);
+            s_in[r * 72 + c] = img[(size_t)gy * pitch + gx];
+        }
     }
     __syncthreads();
-    for (int k = tid; k < 22 * 64; k += 256) {
-        const int yy = k >> 6, xx = k & 63;
-        int s = 0;
+    const int K0 = P.blurK[0], K1 = P.blurK[1], K2 = P.blurK[2], K3 = P.blurK[3];
+    for (int k = tid; k < rows * 16; k += 256) {  // row pass: 4 outputs from 10 input bytes
+        const int r = k >> 4, g = k & 15;
+        const uint8_t* in = &s_in[r * 72 + g * 4 + 1];  // output x = x0 + 4g + j reads bytes (4g + j + 1) .. +6
+        int v[10];
 #pragma unroll
-        for (int j = 0; j < 7; ++j) s += P.blurK[j] * s_in[yy][xx + j];
-        s_row[yy][xx] = (uint16_t)s;
+        for (int j = 0; j < 10; ++j) v[j] = in[j];
+        uint16_t o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            o[j] = (uint16_t)(K0 * (v[j] + v[j + 6]) + K1 * (v[j + 1] + v[j + 5]) + K2 * (v[j + 2] + v[j + 4]) + K3 * v[j + 3]);
+        *reinterpret_cast<uint2*>(&s_row[r * 64 + g * 4]) = make_uint2((uint32_t)o[0] | ((uint32_t)o[1] << 16), (uint32_t)o[2] | ((uint32_t)o[3] << 16));
     }
     __syncthreads();
-    const int oy = tid >> 4, ox = (tid & 15) * 4;
-    if (y0 + oy >= L.h || x0 + ox >= L.pitch) return;
-    uint32_t packed = 0;
+    const int orows = rows - 6;
+    uint8_t* dst = blur + (size_t)frame * blur_fstride + L.blur_off;
+    for (int k = tid; k < orows * 16; k += 256) {  // column pass
+        const int oy = k >> 4, g = k & 15;
+        if (x0 + g * 4 >= L.pitch) continue;
+        int acc[4] = {0, 0, 0, 0};
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        int s = 0;
+        for (int j = 0; j < 7; ++j) {
+            const uint2 q = *reinterpret_cast<const uint2*>(&s_row[(oy + j) * 64 + g * 4]);
+            const int kk = P.blurK[j];
+            acc[0] += kk * (int)(q.x & 0xffff); acc[1] += kk * (int)(q.x >> 16);
+            acc[2] += kk * (int)(q.y & 0xffff); acc[3] += kk * (int)(q.y >> 16);
+        }
+        uint32_t packed = 0;
 #pragma unroll
-        for (int k = 0; k < 7; ++k) s += P.blurK[k] * (int)s_row[oy + k][ox + j];
-        int v = (s + (1 << 15)) >> 16;
-        v = v > 255 ? 255 : v;
-        packed |= (uint32_t)v << (8 * j);
+        for (int j = 0; j < 4; ++j) {
+            int v = (acc[j] + (1 << 15)) >> 16;
+            v = v > 255 ? 255 : v;
+            packed |= (uint32_t)v << (8 * j);
+        }
+        *reinterpret_cast<uint32_t*>(dst + (size_t)(y0 + oy) * L.pitch + x0 + g * 4) = packed;
     }
-    uint8_t* dst = blur + (size_t)frame * blur_fstride + L.blur_off + (size_t)(y0 + oy) * L.pitch + x0 + ox;
-    *reinterpret_cast<uint32_t*>(dst) = packed;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -160,7 +160,10 @@ struct pslfe_line {
         dim3 grid((P.W + 63) / 64, (P.H + 3) / 4, F);
         {
             PSL_STAGE_BEGIN(ctx, "line.lsd_scale");
-            k_lsd_scale<<<grid, 256, 0, st>>>(P, d_gray, stride, frame_stride, d_scaled);
+            if (getenv("PSLFE_LSD_SCALE_SIMPLE"))
+                k_lsd_scale<<<grid, 256, 0, st>>>(P, d_gray, stride, frame_stride, d_scaled);
+            else
+                k_lsd_scale_tiled<<<dim3((P.W + 63) / 64, (P.H + 15) / 16, F), 256, 0, st>>>(P, d_gray, stride, frame_stride, d_scaled);
             PSL_STAGE_END(ctx, "line.lsd_scale");
         }
         {

@@ -7,12 +7,13 @@
 //   BFMatcher(NORM_HAMMING).knnMatch(k=2) in LSDmatcher::matchNNR  add_src/LSDmatcher.cpp:354-376
 //
 // The reference matchers are sequential: a keypoint taken by a map point with observations is
-// skipped by every LATER query (src/ORBmatcher.cc:1401-1403).  k_window_match reproduces that
+// skipped by every LATER query (src/ORBmatcher.cc:1401-1403).  k_window_eval + k_window_resolve reproduce that
 // exactly with a fixpoint: every query picks its best candidate among those not taken by an
 // EARLIER query; "taken by" is recomputed from the current picks until nothing changes.  By
 // induction over the query index the fixpoint is the sequential result.
 #include <string.h>
 
+#include <algorithm>
 #include <vector>
 
 #include "pslfe_internal.h"
@@ -151,95 +152,197 @@ struct MatchArgs {
     int* match;
     int* assigned;
     int* nmatches;
+    uint32_t* topk;   // [pair][qstride][4]: the 4 smallest keys (dist << 16 | CSR position) of every query
+    uint8_t* more;    // [pair][qstride]: the query has more than 4 gated candidates
 };
 
-// MODE 0: SearchByProjection(cur,last); MODE 1: SearchByProjection(F, MapPoints).
-// One workgroup (16 waves) per frame; one wave per query at a time; lane l walks grid column
-// nMinCellX + l, whose cells nMinCellY..nMaxCellY are one contiguous CSR run.
+#define PSL_KEY_INF 0xffffffffu
+
+__device__ __forceinline__ void psl_top4_insert(uint32_t (&t)[4], uint32_t key) {
+    if (key < t[3]) {
+        t[3] = key;
+        if (t[3] < t[2]) { const uint32_t u = t[2]; t[2] = t[3]; t[3] = u; }
+        if (t[2] < t[1]) { const uint32_t u = t[1]; t[1] = t[2]; t[2] = u; }
+        if (t[1] < t[0]) { const uint32_t u = t[0]; t[0] = t[1]; t[1] = u; }
+    }
+}
+
+struct FrameView {
+    const PslKeyPoint* kps;
+    const uint32_t* desc;
+    const float* uright;
+    const int* gstart;
+    const int* gidx;
+    FrameMeta M;
+    int n;
+};
+
+__device__ __forceinline__ FrameView psl_frame_view(const FrameStore& S, int slot) {
+    FrameView V;
+    V.M = S.meta[slot];
+    V.kps = S.kps + (size_t)slot * S.cap;
+    V.desc = reinterpret_cast<const uint32_t*>(S.desc + (size_t)slot * S.cap * 32);
+    V.uright = S.uright + (size_t)slot * S.cap;
+    V.gstart = S.gstart + (size_t)slot * (PSL_GRID_CELLS + 1);
+    V.gidx = S.gidx + (size_t)slot * S.cap;
+    V.n = V.M.n < PSL_QMAX ? V.M.n : PSL_QMAX;
+    return V;
+}
+
+// One wave scans the GetFeaturesInArea window of one query (src/Frame.cc:985-1038): lane l walks grid
+// column nMinCellX + l, whose cells nMinCellY..nMaxCellY are one contiguous CSR run.  Returns (in every
+// lane) the 4 smallest keys among the candidates that pass the level / window / stereo gates and are
+// neither taken initially nor (blocker != NULL) taken by an earlier query; *ncand = their number.
+__device__ void psl_window_scan(const FrameView& V, const PslProjQuery& q, const uint32_t* qd, const uint8_t* taken, const int* blocker,
+                                int qi, uint32_t (&t)[4], int* ncand) {
+    const int lane = threadIdx.x & 63;
+    const FrameMeta& M = V.M;
+    const float r = q.radius;
+    const int minCX = max(0, (int)__builtin_floorf(PSL_FMUL(PSL_FSUB(PSL_FSUB(q.u, M.minX), r), M.invW)));
+    const int maxCX = min(PSL_GRID_COLS - 1, (int)__builtin_ceilf(PSL_FMUL(PSL_FADD(PSL_FSUB(q.u, M.minX), r), M.invW)));
+    const int minCY = max(0, (int)__builtin_floorf(PSL_FMUL(PSL_FSUB(PSL_FSUB(q.v, M.minY), r), M.invH)));
+    const int maxCY = min(PSL_GRID_ROWS - 1, (int)__builtin_ceilf(PSL_FMUL(PSL_FADD(PSL_FSUB(q.v, M.minY), r), M.invH)));
+    t[0] = t[1] = t[2] = t[3] = PSL_KEY_INF;
+    int cnt = 0;
+    const bool window = minCX < PSL_GRID_COLS && maxCX >= 0 && minCY < PSL_GRID_ROWS && maxCY >= 0;
+    const int ix = minCX + lane;
+    if (window && ix <= maxCX) {
+        const bool checkLevels = (q.min_level > 0) || (q.max_level >= 0);
+        const int p1 = V.gstart[ix * PSL_GRID_ROWS + maxCY + 1];
+        for (int p = V.gstart[ix * PSL_GRID_ROWS + minCY]; p < p1; ++p) {
+            const int i2 = V.gidx[p];
+            const PslKeyPoint kp = V.kps[i2];
+            if (checkLevels) {
+                if (kp.octave < q.min_level) continue;
+                if (q.max_level >= 0 && kp.octave > q.max_level) continue;
+            }
+            if (!(__builtin_fabsf(PSL_FSUB(kp.x, q.u)) < r && __builtin_fabsf(PSL_FSUB(kp.y, q.v)) < r)) continue;
+            if (i2 >= V.n) continue;
+            if (taken && taken[i2]) continue;                 // already holds a map point with observations (:1401-1403)
+            if (blocker && blocker[i2] < qi) continue;        // taken by an earlier query of this call
+            const float ur = V.uright[i2];
+            if (ur > 0 && __builtin_fabsf(PSL_FSUB(q.ur, ur)) > r) continue;  // (:1405-1411)
+            psl_top4_insert(t, ((uint32_t)psl_hamming256(qd, V.desc + (size_t)i2 * 8) << 16) | (uint32_t)p);
+            ++cnt;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const uint32_t a0 = __shfl_xor(t[0], o), a1 = __shfl_xor(t[1], o), a2 = __shfl_xor(t[2], o), a3 = __shfl_xor(t[3], o);
+        psl_top4_insert(t, a0); psl_top4_insert(t, a1); psl_top4_insert(t, a2); psl_top4_insert(t, a3);
+        cnt += __shfl_xor(cnt, o);
+    }
+    *ncand = cnt;
+}
+
+// Pass 1 (wide): every query of every pair in parallel, one wave each; ignores first-come blocking.
+__global__ __launch_bounds__(256) void k_window_eval(MatchArgs A) {
+    const int pair = blockIdx.y, qi = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    int nq = A.nq_arr ? A.nq_arr[pair] : A.nq_single;
+    nq = min(min(nq, A.qstride), PSL_QMAX);
+    if (qi >= nq) return;
+    const FrameView V = psl_frame_view(A.S, A.slot0 + pair);
+    const PslProjQuery q = A.q[(size_t)pair * A.qstride + qi];
+    const uint32_t* QD = reinterpret_cast<const uint32_t*>(A.qdesc + ((size_t)pair * A.qstride + qi) * 32);
+    uint32_t qd[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) qd[k] = QD[k];
+    uint32_t t[4];
+    int cnt;
+    psl_window_scan(V, q, qd, A.taken ? A.taken + (size_t)pair * A.S.cap : nullptr, nullptr, qi, t, &cnt);
+    if (lane == 0) {
+        uint32_t* o = A.topk + ((size_t)pair * A.qstride + qi) * 4;
+        o[0] = t[0]; o[1] = t[1]; o[2] = t[2]; o[3] = t[3];
+        A.more[(size_t)pair * A.qstride + qi] = cnt > 4;
+    }
+}
+
+// Pass 2: one workgroup per frame resolves the sequential semantics by a fixpoint on "taken by an earlier
+// query" using the cached top-4 lists (thread per query); a query whose whole list is blocked while it has
+// more candidates is re-scanned in full by a wave (rare).  Then the rotation histogram and the outputs.
+// MODE 0: SearchByProjection(cur,last) (:1328-1470); MODE 1: SearchByProjection(F, MapPoints) (:45-129).
 template <int MODE>
-__global__ __launch_bounds__(1024) void k_window_match(MatchArgs A) {
+__global__ __launch_bounds__(1024) void k_window_resolve(MatchArgs A) {
     __shared__ int s_choice[PSL_QMAX];
     __shared__ int s_blocker[PSL_QMAX];
     __shared__ uint8_t s_bin[PSL_QMAX];
+    __shared__ uint8_t s_slow[PSL_QMAX];
     __shared__ int s_hist[PSL_HISTO];
     __shared__ int s_ind[3];
-    __shared__ int s_flag[2];  // 0: changed, 1: nmatches
+    __shared__ int s_flag[3];  // 0: changed, 1: nmatches, 2: any slow
 
     const int pair = blockIdx.x, slot = A.slot0 + pair, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const FrameStore& S = A.S;
-    const FrameMeta M = S.meta[slot];
-    const PslKeyPoint* kps = S.kps + (size_t)slot * S.cap;
-    const uint32_t* desc = reinterpret_cast<const uint32_t*>(S.desc + (size_t)slot * S.cap * 32);
-    const float* uright = S.uright + (size_t)slot * S.cap;
-    const int* gstart = S.gstart + (size_t)slot * (PSL_GRID_CELLS + 1);
-    const int* gidx = S.gidx + (size_t)slot * S.cap;
+    const FrameView V = psl_frame_view(S, slot);
+    const int n = V.n;
     int nq = A.nq_arr ? A.nq_arr[pair] : A.nq_single;
-    nq = nq < A.qstride ? nq : A.qstride;
-    nq = nq < PSL_QMAX ? nq : PSL_QMAX;
-    const int n = M.n < PSL_QMAX ? M.n : PSL_QMAX;
+    nq = min(min(nq, A.qstride), PSL_QMAX);
     const PslProjQuery* Q = A.q + (size_t)pair * A.qstride;
     const uint32_t* QD = reinterpret_cast<const uint32_t*>(A.qdesc + (size_t)pair * A.qstride * 32);
     const uint8_t* taken = A.taken ? A.taken + (size_t)pair * S.cap : nullptr;
+    const uint32_t* TK = A.topk + (size_t)pair * A.qstride * 4;
+    const uint8_t* MORE = A.more + (size_t)pair * A.qstride;
 
-    for (int i = tid; i < nq; i += 1024) s_choice[i] = -2;  // -2: not evaluated yet
-    for (int i = tid; i < n; i += 1024) s_blocker[i] = (taken && taken[i]) ? -1 : 0x7fffffff;
+    for (int i = tid; i < nq; i += 1024) s_choice[i] = -2;
+    for (int i = tid; i < n; i += 1024) s_blocker[i] = 0x7fffffff;
     __syncthreads();
 
+    // decide a query from its two best non-blocked keys
+    auto decide = [&](uint32_t k1, uint32_t k2) -> int {
+        if (k1 == PSL_KEY_INF) return -1;
+        const int bestDist = (int)(k1 >> 16), bestIdx = V.gidx[k1 & 0xffff];
+        bool ok = bestDist <= PSL_TH_HIGH;
+        if (MODE == 1 && ok && k2 != PSL_KEY_INF) {
+            const int bestDist2 = (int)(k2 >> 16);
+            const int l1 = V.kps[bestIdx].octave, l2 = V.kps[V.gidx[k2 & 0xffff]].octave;
+            if (l1 == l2 && (float)bestDist > PSL_FMUL(A.nnratio, (float)bestDist2)) ok = false;  // (:118-121)
+        }
+        return ok ? bestIdx : -1;
+    };
+
     for (int iter = 0; iter <= nq; ++iter) {
-        if (tid == 0) s_flag[0] = 0;
+        if (tid == 0) { s_flag[0] = 0; s_flag[2] = 0; }
         __syncthreads();
-        for (int qi = wave; qi < nq; qi += 16) {
-            const PslProjQuery q = Q[qi];
-            uint32_t qd[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) qd[k] = QD[(size_t)qi * 8 + k];
-            // GetFeaturesInArea window (src/Frame.cc:990-1004)
-            const float r = q.radius;
-            const int minCX = max(0, (int)__builtin_floorf(PSL_FMUL(PSL_FSUB(PSL_FSUB(q.u, M.minX), r), M.invW)));
-            const int maxCX = min(PSL_GRID_COLS - 1, (int)__builtin_ceilf(PSL_FMUL(PSL_FADD(PSL_FSUB(q.u, M.minX), r), M.invW)));
-            const int minCY = max(0, (int)__builtin_floorf(PSL_FMUL(PSL_FSUB(PSL_FSUB(q.v, M.minY), r), M.invH)));
-            const int maxCY = min(PSL_GRID_ROWS - 1, (int)__builtin_ceilf(PSL_FMUL(PSL_FADD(PSL_FSUB(q.v, M.minY), r), M.invH)));
-            uint32_t k1 = 0xffffffffu, k2 = 0xffffffffu;
-            const bool window = minCX < PSL_GRID_COLS && maxCX >= 0 && minCY < PSL_GRID_ROWS && maxCY >= 0;
-            const int ix = minCX + lane;
-            if (window && ix <= maxCX) {
-                const bool checkLevels = (q.min_level > 0) || (q.max_level >= 0);
-                const int p1 = gstart[ix * PSL_GRID_ROWS + maxCY + 1];
-                for (int p = gstart[ix * PSL_GRID_ROWS + minCY]; p < p1; ++p) {
-                    const int i2 = gidx[p];
-                    const PslKeyPoint kp = kps[i2];
-                    if (checkLevels) {
-                        if (kp.octave < q.min_level) continue;
-                        if (q.max_level >= 0 && kp.octave > q.max_level) continue;
-                    }
-                    if (!(__builtin_fabsf(PSL_FSUB(kp.x, q.u)) < r && __builtin_fabsf(PSL_FSUB(kp.y, q.v)) < r)) continue;
-                    if (i2 >= n || s_blocker[i2] < qi) continue;  // taken by an earlier query (:1401-1403)
-                    const float ur = uright[i2];
-                    if (ur > 0 && __builtin_fabsf(PSL_FSUB(q.ur, ur)) > r) continue;  // (:1405-1411)
-                    const uint32_t key = ((uint32_t)psl_hamming256(qd, desc + (size_t)i2 * 8) << 16) | (uint32_t)p;
-                    if (key < k1) { k2 = k1; k1 = key; } else if (key < k2) k2 = key;
-                }
+        for (int qi = tid; qi < nq; qi += 1024) {  // fast path: cached lists
+            uint32_t k1 = PSL_KEY_INF, k2 = PSL_KEY_INF;
+            int found = 0;
+            bool exhausted = true;  // true if the list ended before we had what we need
+            for (int r = 0; r < 4; ++r) {
+                const uint32_t key = TK[(size_t)qi * 4 + r];
+                if (key == PSL_KEY_INF) break;
+                const int c = V.gidx[key & 0xffff];
+                if (s_blocker[c] < qi) continue;
+                if (found == 0) { k1 = key; found = 1; if (MODE == 0) { exhausted = false; break; } }
+                else { k2 = key; found = 2; exhausted = false; break; }
             }
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) psl_merge2(k1, k2, __shfl_xor(k1, o), __shfl_xor(k2, o));
-            int pick = -1;
-            if (k1 != 0xffffffffu) {
-                const int bestDist = (int)(k1 >> 16), bestIdx = gidx[k1 & 0xffff];
-                bool ok = bestDist <= PSL_TH_HIGH;
-                if (MODE == 1 && ok && k2 != 0xffffffffu) {
-                    const int bestDist2 = (int)(k2 >> 16);
-                    const int l1 = kps[bestIdx].octave, l2 = kps[gidx[k2 & 0xffff]].octave;
-                    if (l1 == l2 && (float)bestDist > PSL_FMUL(A.nnratio, (float)bestDist2)) ok = false;  // (:118-121)
-                }
-                if (ok) pick = bestIdx;
+            const bool slow = exhausted && MORE[qi];  // the list ran out but the window holds more candidates
+            s_slow[qi] = slow;
+            if (slow) s_flag[2] = 1;
+            else {
+                const int pick = decide(k1, k2);
+                if (s_choice[qi] != pick) { s_choice[qi] = pick; s_flag[0] = 1; }
             }
-            if (lane == 0 && s_choice[qi] != pick) { s_choice[qi] = pick; s_flag[0] = 1; }
+        }
+        __syncthreads();
+        if (s_flag[2]) {  // slow path: full window scan with the current blockers, one wave per query
+            for (int qi = wave; qi < nq; qi += 16) {
+                if (!s_slow[qi]) continue;
+                const PslProjQuery q = Q[qi];
+                uint32_t qd[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) qd[k] = QD[(size_t)qi * 8 + k];
+                uint32_t t[4];
+                int cnt;
+                psl_window_scan(V, q, qd, taken, s_blocker, qi, t, &cnt);
+                const int pick = decide(t[0], t[1]);
+                if (lane == 0 && s_choice[qi] != pick) { s_choice[qi] = pick; s_flag[0] = 1; }
+            }
         }
         __syncthreads();
         const int changed = s_flag[0];
         __syncthreads();
         if (!changed) break;
-        for (int i = tid; i < n; i += 1024) s_blocker[i] = (taken && taken[i]) ? -1 : 0x7fffffff;
+        for (int i = tid; i < n; i += 1024) s_blocker[i] = 0x7fffffff;
         __syncthreads();
         for (int qi = tid; qi < nq; qi += 1024) {
             const int c = s_choice[qi];
@@ -258,7 +361,7 @@ __global__ __launch_bounds__(1024) void k_window_match(MatchArgs A) {
         for (int qi = tid; qi < nq; qi += 1024) {
             const int c = s_choice[qi];
             if (c < 0) continue;
-            float rot = PSL_FSUB(Q[qi].angle, kps[c].angle);
+            float rot = PSL_FSUB(Q[qi].angle, V.kps[c].angle);
             if (rot < 0.0f) rot = PSL_FADD(rot, 360.0f);
             int bin = (int)__builtin_roundf(PSL_FMUL(rot, factor));
             if (bin == PSL_HISTO) bin = 0;
@@ -270,10 +373,10 @@ __global__ __launch_bounds__(1024) void k_window_match(MatchArgs A) {
         if (tid == 0) {  // ComputeThreeMaxima (:1601-1645)
             int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
             for (int i = 0; i < PSL_HISTO; ++i) {
-                const int s = s_hist[i];
-                if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
-                else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
-                else if (s > max3) { max3 = s; ind3 = i; }
+                const int sz = s_hist[i];
+                if (sz > max1) { max3 = max2; max2 = max1; max1 = sz; ind3 = ind2; ind2 = ind1; ind1 = i; }
+                else if (sz > max2) { max3 = max2; max2 = sz; ind3 = ind2; ind2 = i; }
+                else if (sz > max3) { max3 = sz; ind3 = i; }
             }
             if ((float)max2 < PSL_FMUL(0.1f, (float)max1)) { ind2 = -1; ind3 = -1; }
             else if ((float)max3 < PSL_FMUL(0.1f, (float)max1)) { ind3 = -1; }
@@ -308,7 +411,7 @@ __global__ __launch_bounds__(1024) void k_window_match(MatchArgs A) {
     __syncthreads();
     if (A.assigned) {
         int* asg = A.assigned + (size_t)pair * S.cap;
-        for (int i = tid; i < M.n; i += 1024) asg[i] = i < n ? s_blocker[i] : -1;
+        for (int i = tid; i < V.M.n; i += 1024) asg[i] = i < n ? s_blocker[i] : -1;
     }
     if (tid == 0) A.nmatches[pair] = s_flag[1];
 }
@@ -350,6 +453,10 @@ struct pslfe_frame {
     int* d_match = nullptr;
     int* d_assigned = nullptr;
     int* d_nm = nullptr;
+    uint32_t* d_topk = nullptr;  // [max_frames][cap][4]
+    uint8_t* d_more = nullptr;   // [max_frames][cap]
+    uint32_t* d_topk1 = nullptr; // [PSL_QMAX][4] for the host-pointer entry points
+    uint8_t* d_more1 = nullptr;
     std::vector<char> slot_set;
 };
 
@@ -378,9 +485,11 @@ int host_search(pslfe_frame* f, int slot, const PslProjQuery* queries, const uin
     A.slot0 = slot; A.q = f->d_q; A.qdesc = f->d_qdesc; A.nq_arr = nullptr; A.nq_single = nq; A.qstride = PSL_QMAX;
     A.taken = taken ? f->d_taken : nullptr; A.check_ori = check_ori; A.nnratio = nnratio;
     A.match = f->d_match; A.assigned = f->d_assigned; A.nmatches = f->d_nm;
+    A.topk = f->d_topk1; A.more = f->d_more1;
     {
         PSL_STAGE_BEGIN(f->ctx, "match.window");
-        if (mode == 0) k_window_match<0><<<1, 1024, 0, st>>>(A); else k_window_match<1><<<1, 1024, 0, st>>>(A);
+        k_window_eval<<<dim3((nq + 3) / 4, 1), 256, 0, st>>>(A);
+        if (mode == 0) k_window_resolve<0><<<1, 1024, 0, st>>>(A); else k_window_resolve<1><<<1, 1024, 0, st>>>(A);
         PSL_STAGE_END(f->ctx, "match.window");
     }
     PSL_HIP(hipGetLastError());
@@ -420,6 +529,10 @@ int pslfe_frame_create(pslfe_ctx* ctx, int max_keypoints, int max_frames, pslfe_
     A((void**)&f->d_match, PSL_QMAX * sizeof(int));
     A((void**)&f->d_assigned, K * sizeof(int));
     A((void**)&f->d_nm, sizeof(int));
+    A((void**)&f->d_topk, F * K * 4 * sizeof(uint32_t));
+    A((void**)&f->d_more, F * K);
+    A((void**)&f->d_topk1, (size_t)PSL_QMAX * 4 * sizeof(uint32_t));
+    A((void**)&f->d_more1, PSL_QMAX);
     if (e != hipSuccess) {
         pslfe_set_error("pslfe_frame_create: hipMalloc failed: %s", hipGetErrorString(e));
         pslfe_frame_destroy(f);
@@ -437,6 +550,7 @@ void pslfe_frame_destroy(pslfe_frame* f) {
     hipFree(f->S.kps); hipFree(f->S.desc); hipFree(f->S.uright); hipFree(f->S.cellof); hipFree(f->S.gstart);
     hipFree(f->S.gidx); hipFree(f->S.meta); hipFree(f->d_q); hipFree(f->d_qdesc); hipFree(f->d_taken);
     hipFree(f->d_match); hipFree(f->d_assigned); hipFree(f->d_nm);
+    hipFree(f->d_topk); hipFree(f->d_more); hipFree(f->d_topk1); hipFree(f->d_more1);
     delete f;
 }
 
@@ -528,9 +642,12 @@ int pslfe_orb_search_by_projection_last_device(pslfe_frame* cur, int slot0, int 
     MatchArgs A;
     A.S = cur->S; A.slot0 = slot0; A.q = d_queries; A.qdesc = d_qdesc; A.nq_arr = d_nq; A.nq_single = 0; A.qstride = qstride;
     A.taken = nullptr; A.check_ori = check_orientation; A.nnratio = 0.f; A.match = d_match; A.assigned = nullptr; A.nmatches = d_nmatches;
+    PSL_REQUIRE(qstride <= cur->cap && npairs <= cur->max_frames, PSLFE_E_CAPACITY, "search_by_projection_last_device: qstride %d > capacity %d", qstride, cur->cap);
+    A.topk = cur->d_topk; A.more = cur->d_more;
     {
         PSL_STAGE_BEGIN(cur->ctx, "match.window");
-        k_window_match<0><<<npairs, 1024, 0, cur->ctx->stream>>>(A);
+        k_window_eval<<<dim3((std::min(qstride, PSL_QMAX) + 3) / 4, npairs), 256, 0, cur->ctx->stream>>>(A);
+        k_window_resolve<0><<<npairs, 1024, 0, cur->ctx->stream>>>(A);
         PSL_STAGE_END(cur->ctx, "match.window");
     }
     PSL_HIP(hipGetLastError());

@@ -161,7 +161,7 @@ struct pslfe_orb {
             L.scale = scale[l];
             L.kpsize = (float)(int)(31 * scale[l]);
             L.tiles_x = (L.w + 63) / 64;
-            L.tiles_y = (L.h + 15) / 16;
+            L.tiles_y = (L.h + PSL_BLUR_TH - 1) / PSL_BLUR_TH;
             L.tile_off = tile_off;
             tile_off += L.tiles_x * L.tiles_y;
         }
