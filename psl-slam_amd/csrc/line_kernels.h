@@ -494,23 +494,24 @@ __device__ int lsdw_region_grow(const LsdW& F, int sx, int sy, double* reg_angle
         }
         const bool cand0 = a != PSL_LSD_NOTDEF;
         const double ad = PSL_DMUL((double)a, PSL_DEG2RAD);
-        for (int ee = 0; ee < nb; ++ee) {
-            int pos = 0;
-            while (true) {
-                const bool ok = cand0 && e == ee && k >= pos && !lsdw_used(F, c) && lsdw_aligned(ad, reg_angle, prec);
-                const unsigned long long m = __ballot(ok);
-                if (!m) break;
-                const int L = __ffsll((long long)m) - 1;
-                const int cL = __shfl(c, L), xL = __shfl(nx, L), yL = __shfl(ny, L);
-                const float csL = __shfl(cs, L), snL = __shfl(sn, L);
-                lsdw_set(F, cL);
-                lsdw_push(F, reg_size, (uint32_t)xL | ((uint32_t)yL << 16));
-                ++reg_size;
-                sumdx = PSL_FADD(sumdx, csL);
-                sumdy = PSL_FADD(sumdy, snL);
-                reg_angle = PSL_DMUL((double)psl_fast_atan2(sumdy, sumdx), PSL_DEG2RAD);
-                pos = (L - 9 * ee) + 1;
-            }
+        // lanes are ordered (entry, neighbour) exactly as the reference visits them, so one cursor over the
+        // lane index replaces the per-entry loops: take the first lane >= cursor that is still unused and
+        // aligned with the CURRENT angle, add it, move the cursor behind it, re-test the rest.
+        int cursor = 0;
+        while (true) {
+            const bool ok = cand0 && F.lane >= cursor && !lsdw_used(F, c) && lsdw_aligned(ad, reg_angle, prec);
+            const unsigned long long m = __ballot(ok);
+            if (!m) break;
+            const int L = __ffsll((long long)m) - 1;
+            const int cL = __shfl(c, L), xL = __shfl(nx, L), yL = __shfl(ny, L);
+            const float csL = __shfl(cs, L), snL = __shfl(sn, L);
+            lsdw_set(F, cL);
+            lsdw_push(F, reg_size, (uint32_t)xL | ((uint32_t)yL << 16));
+            ++reg_size;
+            sumdx = PSL_FADD(sumdx, csL);
+            sumdy = PSL_FADD(sumdy, snL);
+            reg_angle = PSL_DMUL((double)psl_fast_atan2(sumdy, sumdx), PSL_DEG2RAD);
+            cursor = L + 1;
         }
         i += nb;
     }

@@ -131,7 +131,7 @@ __device__ __forceinline__ int psl_fast_score(const uint8_t* c, const int tp) {
     return max(A, -B) - 1;
 }
 
-__global__ __launch_bounds__(256) void k_fast_cells(OrbParams P, FrameSrc S, int* __restrict__ cellcnt,
+__global__ __launch_bounds__(256, 8) void k_fast_cells(OrbParams P, FrameSrc S, int* __restrict__ cellcnt,
                                                      uint32_t* __restrict__ cellcand) {
     __shared__ uint8_t s_tile[(PSL_MAXCELL + 6) * PSL_FAST_TP];
     __shared__ uint8_t s_score[(PSL_MAXCELL + 2) * PSL_FAST_SP];
