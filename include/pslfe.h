@@ -279,6 +279,29 @@ int pslfe_orb_search_by_projection_last_device(pslfe_frame* cur, int slot0, int 
 int pslfe_line_match_nnr(pslfe_ctx* ctx, const uint8_t* desc1, int n1, const uint8_t* desc2, int n2, float nnr,
                          int32_t* matches12, int* nmatches);
 
+/* == LSDmatcher::SearchByGeomNApearance(CurrentFrame, LastFrame, desc_th) add_src/LSDmatcher.cpp:36-110
+ *    (TrackWithMotionModel, src/Tracking.cc:1183): matchNNR, then for last-frame lines that own a map
+ *    line (has_mapline[i1] != 0) the 20-degree direction gate and the 10 %-of-image end-point gate.
+ *    matches12[n1] as the reference leaves it; assigned[n2] = last-frame line whose map line is given to
+ *    current line i2 (or -1); *lmatches = return value. */
+int pslfe_line_search_by_geom_appearance(pslfe_ctx* ctx, const PslKeyLine* kl_last, const uint8_t* desc_last, int n1,
+                                         const PslKeyLine* kl_cur, const uint8_t* desc_cur, int n2, const uint8_t* has_mapline,
+                                         float desc_th, float min_x, float max_x, float min_y, float max_y, int32_t* matches12,
+                                         int32_t* assigned, int* lmatches);
+/* == LSDmatcher::FrameBFMatch(ldesc1, ldesc2, LineMatches, TH) add_src/LSDmatcher.cpp:492-516 with
+ *    lineDescriptorMAD :660-685: kNN-2, gap d1-d0 above half its MAD, d0 < TH, d0 < mfNNratio*d1. */
+int pslfe_line_frame_bf_match(pslfe_ctx* ctx, const uint8_t* desc1, int n1, const uint8_t* desc2, int n2, float nnratio, float TH,
+                              int32_t* line_matches);
+/* == Map::AssociatePlanesByBoundary(pF, dTh, aTh) src/Map.cc:204-272 (live != 0; called from
+ *    src/Tracking.cc:967,1209,1329,1531) / InsectLineMatch::SearchMapInsectline
+ *    add_src/InsectlineMatch.cpp:9-59 (live == 0; no live caller upstream).  planes: n x 4 world planes of
+ *    the frame's LIL pairs (ComputeWorldPlane); points: n x 5 x 3 doubles = start/end of line i, start/end
+ *    of line j, 3-D intersection; map_planes: m x 4 in the caller's iteration order (upstream iterates a
+ *    std::set of pointers); map_bad: isBad() flags (dead variant only, may be NULL).  The live variant
+ *    keeps upstream's running threshold (dTh = dis, shared by all planes) and counts every association. */
+int pslfe_associate_planes(pslfe_ctx* ctx, const float* planes, const double* points, int nplanes, const float* map_planes,
+                           const uint8_t* map_bad, int nmap, float dTh, float aTh, int live, int32_t* assoc, int* nmatches);
+
 #ifdef __cplusplus
 }
 #endif

@@ -79,6 +79,13 @@ int pso_line_extract(const uint8_t* gray, int w, int h, int stride, int nLSDFeat
                      double* lineEq, int cap);
 int pso_lil_pair(const float* L, int rows, float radius, float fanThr, int imgCols, int imgRows, float* fans, int cap);
 
+int pso_search_by_geom_appearance(const PsoKeyLine* kl_last, const uint8_t* d_last, int n1, const PsoKeyLine* kl_cur, const uint8_t* d_cur,
+                                  int n2, const uint8_t* has_mapline, float desc_th, float minX, float maxX, float minY, float maxY,
+                                  int* matches12, int* assigned);
+void pso_frame_bf_match(const uint8_t* d1, int n1, const uint8_t* d2, int n2, float nnratio, float TH, int* lineMatches);
+int pso_associate_planes(const float* planes, const double* pts, int N, const float* map, const uint8_t* bad, int M, float dTh, float aTh,
+                         int live, int* assoc);
+
 #ifdef __cplusplus
 }
 #endif

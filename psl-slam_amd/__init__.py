@@ -545,3 +545,48 @@ LINEextractor.debug_sobel = _line_debug_sobel
 LINEextractor.pair = _line_pair
 LINEextractor.pair_batch_device = _line_pair_batch_device
 LINEextractor.fans_fetch = _line_fans_fetch
+
+
+def _lsd_search_by_geom_appearance(self, kl_last, desc_last, kl_cur, desc_cur, has_mapline, desc_th, bounds):
+    """LSDmatcher::SearchByGeomNApearance(CurrentFrame, LastFrame, desc_th) -> (lmatches, matches12, assigned).
+    bounds = (mnMinX, mnMaxX, mnMinY, mnMaxY)."""
+    k1 = np.ascontiguousarray(kl_last, KEYLINE_DTYPE)
+    k2 = np.ascontiguousarray(kl_cur, KEYLINE_DTYPE)
+    d1 = np.ascontiguousarray(desc_last, np.uint8).reshape(-1, 32)
+    d2 = np.ascontiguousarray(desc_cur, np.uint8).reshape(-1, 32)
+    hm = np.ascontiguousarray(has_mapline, np.uint8)
+    m12 = np.full(max(len(k1), 1), -1, np.int32)
+    asg = np.full(max(len(k2), 1), -1, np.int32)
+    n = C.c_int()
+    _check(lib().pslfe_line_search_by_geom_appearance(self.ctx._h, _ptr(k1), _ptr(d1), C.c_int(len(k1)), _ptr(k2), _ptr(d2), C.c_int(len(k2)),
+                                                      _ptr(hm), C.c_float(desc_th), *[C.c_float(b) for b in bounds], _ptr(m12), _ptr(asg),
+                                                      C.byref(n)), "pslfe_line_search_by_geom_appearance")
+    return n.value, m12[:len(k1)], asg[:len(k2)]
+
+
+def _lsd_frame_bf_match(self, ldesc1, ldesc2, TH):
+    """LSDmatcher::FrameBFMatch(ldesc1, ldesc2, LineMatches, TH) -> LineMatches."""
+    d1 = np.ascontiguousarray(ldesc1, np.uint8).reshape(-1, 32)
+    d2 = np.ascontiguousarray(ldesc2, np.uint8).reshape(-1, 32)
+    lm = np.full(max(len(d1), 1), -1, np.int32)
+    _check(lib().pslfe_line_frame_bf_match(self.ctx._h, _ptr(d1), C.c_int(len(d1)), _ptr(d2), C.c_int(len(d2)), C.c_float(self.mfNNratio),
+                                           C.c_float(TH), _ptr(lm)), "pslfe_line_frame_bf_match")
+    return lm[:len(d1)]
+
+
+LSDmatcher.SearchByGeomNApearance = _lsd_search_by_geom_appearance
+LSDmatcher.FrameBFMatch = _lsd_frame_bf_match
+
+
+def associate_planes(planes, points, map_planes, dTh, aTh, live=True, map_bad=None, ctx=None):
+    """Map::AssociatePlanesByBoundary (live) / InsectLineMatch::SearchMapInsectline (dead) -> (nmatches, assoc)."""
+    ctx = ctx or default_context()
+    p = np.ascontiguousarray(planes, np.float32).reshape(-1, 4)
+    q = np.ascontiguousarray(points, np.float64).reshape(-1, 15)
+    m = np.ascontiguousarray(map_planes, np.float32).reshape(-1, 4)
+    b = None if map_bad is None else np.ascontiguousarray(map_bad, np.uint8)
+    assoc = np.full(max(len(p), 1), -1, np.int32)
+    n = C.c_int()
+    _check(lib().pslfe_associate_planes(ctx._h, _ptr(p), _ptr(q), C.c_int(len(p)), _ptr(m), _ptr(b), C.c_int(len(m)), C.c_float(dTh),
+                                        C.c_float(aTh), C.c_int(1 if live else 0), _ptr(assoc), C.byref(n)), "pslfe_associate_planes")
+    return n.value, assoc[:len(p)]

@@ -269,3 +269,35 @@ def lil_pair(lines, radius, fan_thr, cols, rows, cap=65536):
     L.pso_lil_pair.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_int]
     n = L.pso_lil_pair(_p(lines), len(lines), radius, fan_thr, cols, rows, _p(fans), cap)
     return fans[:n].copy()
+
+
+def search_by_geom_appearance(kl_last, d_last, kl_cur, d_cur, has_mapline, desc_th, bounds):
+    L = load()
+    k1 = np.ascontiguousarray(kl_last, KEYLINE_DTYPE); k2 = np.ascontiguousarray(kl_cur, KEYLINE_DTYPE)
+    d1 = np.ascontiguousarray(d_last, np.uint8).reshape(-1, 32); d2 = np.ascontiguousarray(d_cur, np.uint8).reshape(-1, 32)
+    hm = np.ascontiguousarray(has_mapline, np.uint8)
+    m12 = np.full(max(len(k1), 1), -1, np.int32); asg = np.full(max(len(k2), 1), -1, np.int32)
+    L.pso_search_by_geom_appearance.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_float,
+                                                C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p]
+    n = L.pso_search_by_geom_appearance(_p(k1), _p(d1), len(k1), _p(k2), _p(d2), len(k2), _p(hm), desc_th, *bounds, _p(m12), _p(asg))
+    return n, m12[:len(k1)], asg[:len(k2)]
+
+
+def frame_bf_match(d1, d2, nnratio, TH):
+    L = load()
+    d1 = np.ascontiguousarray(d1, np.uint8).reshape(-1, 32); d2 = np.ascontiguousarray(d2, np.uint8).reshape(-1, 32)
+    lm = np.full(max(len(d1), 1), -1, np.int32)
+    L.pso_frame_bf_match.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_void_p]
+    L.pso_frame_bf_match(_p(d1), len(d1), _p(d2), len(d2), nnratio, TH, _p(lm))
+    return lm[:len(d1)]
+
+
+def associate_planes(planes, points, map_planes, dTh, aTh, live, map_bad=None):
+    L = load()
+    p = np.ascontiguousarray(planes, np.float32).reshape(-1, 4); q = np.ascontiguousarray(points, np.float64).reshape(-1, 15)
+    m = np.ascontiguousarray(map_planes, np.float32).reshape(-1, 4)
+    b = None if map_bad is None else np.ascontiguousarray(map_bad, np.uint8)
+    assoc = np.full(max(len(p), 1), -1, np.int32)
+    L.pso_associate_planes.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_int, C.c_void_p]
+    n = L.pso_associate_planes(_p(p), _p(q), len(p), _p(m), _p(b), len(m), dTh, aTh, int(live), _p(assoc))
+    return n, assoc[:len(p)]
