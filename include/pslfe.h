@@ -302,6 +302,31 @@ int pslfe_line_frame_bf_match(pslfe_ctx* ctx, const uint8_t* desc1, int n1, cons
 int pslfe_associate_planes(pslfe_ctx* ctx, const float* planes, const double* points, int nplanes, const float* map_planes,
                            const uint8_t* map_bad, int nmap, float dTh, float aTh, int live, int32_t* assoc, int* nmatches);
 
+/* One projected map line of LSDmatcher::SearchByProjection: what Tracking knows after isInFrustum. */
+typedef struct PslLineQuery {
+    float x1, y1, x2, y2;   /* mTrackProjX1, mTrackProjY1, mTrackProjX2, mTrackProjY2                     */
+    float radius;           /* th (add_src/LSDmatcher.cpp:151) or RadiusByViewingCos * th (:282-285)       */
+    float th_cos;           /* TH of GetFeaturesInAreaForLine: 0.96 (:155) or the default 0.998           */
+    float vx, vy;           /* mode 0: LastFrame line direction ePointInOctave - sPointInOctave (:181-183) */
+    float length;           /* mode 0: LastFrame.mvKeylinesUn[i].lineLength (:192-196)                     */
+    int32_t blocks;         /* the map line has Observations() > 0                                         */
+    double wdir[3];         /* mode 1: MapLine::GetNormal() (:293)                                         */
+} PslLineQuery;
+
+/* == LSDmatcher::SearchByProjection(CurrentFrame, LastFrame, th) add_src/LSDmatcher.cpp:112-215 (mode 0)
+ *    and LSDmatcher::SearchByProjection(F, vpMapLines, eval_orient, th) :260-352 (mode 1), after the host
+ *    has projected the map lines; includes Frame::AssignFeaturesToGridForLine (src/Frame.cc:286-309, with
+ *    the Bresenham iterator of add_src/lineIterator.cpp) and Frame::GetFeaturesInAreaForLine (:752-826).
+ *    kls/desc/lineEq: the frame's mvKeylinesUn, mLdesc, mvKeyLineFunctions; dir3d (mode 1): n x 3 doubles
+ *    mvLines3D[i].first - .second.  taken (may be NULL), match, assigned, *nmatches as for the ORB
+ *    matchers.  grid_start (CELLS+1) / grid_idx / grid_n (may be NULL): tap of mGridForLine as CSR with
+ *    cell = ix*48+iy, for parity tests. */
+int pslfe_line_search_by_projection(pslfe_ctx* ctx, const PslKeyLine* kls, const uint8_t* desc, const double* lineEq,
+                                    const double* dir3d, int n, float min_x, float min_y, float max_x, float max_y,
+                                    const PslLineQuery* queries, const uint8_t* qdesc, int nq, const uint8_t* taken, int mode,
+                                    float nnratio, int32_t* match, int32_t* assigned, int* nmatches, int32_t* grid_start,
+                                    int32_t* grid_idx, int grid_cap, int* grid_n);
+
 #ifdef __cplusplus
 }
 #endif

@@ -32,6 +32,14 @@ typedef struct PsoProjQuery {
     int32_t blocks;
 } PsoProjQuery;
 
+typedef struct PsoLineQuery {
+    float x1, y1, x2, y2;   /* mTrackProjX1.. : projected end points */
+    float radius, th_cos;   /* r and TH of GetFeaturesInAreaForLine */
+    float vx, vy, length;   /* mode 0: last frame's line direction (ePoint - sPoint) and lineLength */
+    int32_t blocks;
+    double wdir[3];         /* mode 1: MapLine::GetNormal() */
+} PsoLineQuery;
+
 void* pso_orb_create(int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST);
 void pso_orb_destroy(void* h);
 int pso_orb_extract(void* h, const uint8_t* gray, int w, int hh, int stride, PsoKeyPoint* kps, uint8_t* desc, int cap);
@@ -85,6 +93,11 @@ int pso_search_by_geom_appearance(const PsoKeyLine* kl_last, const uint8_t* d_la
 void pso_frame_bf_match(const uint8_t* d1, int n1, const uint8_t* d2, int n2, float nnratio, float TH, int* lineMatches);
 int pso_associate_planes(const float* planes, const double* pts, int N, const float* map, const uint8_t* bad, int M, float dTh, float aTh,
                          int live, int* assoc);
+
+int pso_line_grid_build(const PsoKeyLine* k, int n, float minX, float minY, float maxX, float maxY, int* start, int* idx, int cap);
+int pso_line_search_by_projection(const PsoKeyLine* k, const uint8_t* desc, const double* eq, const double* dir3d, int n, float minX,
+                                  float minY, float maxX, float maxY, const PsoLineQuery* q, const uint8_t* qdesc, int nq,
+                                  const uint8_t* taken, int mode, float nnratio, int* match, int* assigned);
 
 #ifdef __cplusplus
 }

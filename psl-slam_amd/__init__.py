@@ -590,3 +590,35 @@ def associate_planes(planes, points, map_planes, dTh, aTh, live=True, map_bad=No
     _check(lib().pslfe_associate_planes(ctx._h, _ptr(p), _ptr(q), C.c_int(len(p)), _ptr(m), _ptr(b), C.c_int(len(m)), C.c_float(dTh),
                                         C.c_float(aTh), C.c_int(1 if live else 0), _ptr(assoc), C.byref(n)), "pslfe_associate_planes")
     return n.value, assoc[:len(p)]
+
+
+LINEQUERY_DTYPE = np.dtype([("x1", "<f4"), ("y1", "<f4"), ("x2", "<f4"), ("y2", "<f4"), ("radius", "<f4"), ("th_cos", "<f4"),
+                            ("vx", "<f4"), ("vy", "<f4"), ("length", "<f4"), ("blocks", "<i4"), ("wdir", "<f8", (3,))])
+assert LINEQUERY_DTYPE.itemsize == 64
+
+
+def _lsd_search_by_projection(self, kls, desc, lineEq, bounds, queries, qdesc, mode=0, dir3d=None, taken=None, want_grid=False):
+    """LSDmatcher::SearchByProjection: mode 0 = (CurrentFrame, LastFrame, th), mode 1 = (F, vpMapLines, ...).
+    bounds = (mnMinX, mnMinY, mnMaxX, mnMaxY) -> (nmatches, match, assigned[, grid_start, grid_idx])."""
+    k = np.ascontiguousarray(kls, KEYLINE_DTYPE)
+    d = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+    eq = np.ascontiguousarray(lineEq, np.float64).reshape(-1, 3)
+    q = np.ascontiguousarray(queries, LINEQUERY_DTYPE)
+    qd = np.ascontiguousarray(qdesc, np.uint8).reshape(-1, 32)
+    d3 = None if dir3d is None else np.ascontiguousarray(dir3d, np.float64).reshape(-1, 3)
+    tk = None if taken is None else np.ascontiguousarray(taken, np.uint8)
+    match = np.full(max(len(q), 1), -1, np.int32)
+    asg = np.full(max(len(k), 1), -1, np.int32)
+    nm, gn = C.c_int(), C.c_int()
+    gs = np.zeros(64 * 48 + 1, np.int32) if want_grid else None
+    gi = np.zeros(max(len(k), 1) * 112, np.int32) if want_grid else None
+    _check(lib().pslfe_line_search_by_projection(self.ctx._h, _ptr(k), _ptr(d), _ptr(eq), _ptr(d3), C.c_int(len(k)),
+                                                 *[C.c_float(b) for b in bounds], _ptr(q), _ptr(qd), C.c_int(len(q)), _ptr(tk),
+                                                 C.c_int(mode), C.c_float(self.mfNNratio), _ptr(match), _ptr(asg), C.byref(nm),
+                                                 _ptr(gs), _ptr(gi), C.c_int(0 if gi is None else len(gi)), C.byref(gn)),
+           "pslfe_line_search_by_projection")
+    out = (nm.value, match[:len(q)], asg[:len(k)])
+    return out + (gs, gi[:gn.value]) if want_grid else out
+
+
+LSDmatcher.SearchByProjection = _lsd_search_by_projection

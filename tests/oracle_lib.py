@@ -301,3 +301,31 @@ def associate_planes(planes, points, map_planes, dTh, aTh, live, map_bad=None):
     L.pso_associate_planes.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_int, C.c_void_p]
     n = L.pso_associate_planes(_p(p), _p(q), len(p), _p(m), _p(b), len(m), dTh, aTh, int(live), _p(assoc))
     return n, assoc[:len(p)]
+
+
+LINEQUERY_DTYPE = np.dtype([("x1", "<f4"), ("y1", "<f4"), ("x2", "<f4"), ("y2", "<f4"), ("radius", "<f4"), ("th_cos", "<f4"),
+                            ("vx", "<f4"), ("vy", "<f4"), ("length", "<f4"), ("blocks", "<i4"), ("wdir", "<f8", (3,))])
+
+
+def line_grid_build(kls, bounds):
+    L = load()
+    k = np.ascontiguousarray(kls, KEYLINE_DTYPE)
+    start = np.zeros(64 * 48 + 1, np.int32)
+    idx = np.zeros(max(len(k), 1) * 112, np.int32)
+    L.pso_line_grid_build.argtypes = [C.c_void_p, C.c_int] + [C.c_float] * 4 + [C.c_void_p, C.c_void_p, C.c_int]
+    n = L.pso_line_grid_build(_p(k), len(k), *bounds, _p(start), _p(idx), len(idx))
+    return start, idx[:n]
+
+
+def line_search_by_projection(kls, desc, eq, bounds, queries, qdesc, mode=0, dir3d=None, taken=None, nnratio=0.95):
+    L = load()
+    k = np.ascontiguousarray(kls, KEYLINE_DTYPE); d = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+    e = np.ascontiguousarray(eq, np.float64).reshape(-1, 3)
+    q = np.ascontiguousarray(queries, LINEQUERY_DTYPE); qd = np.ascontiguousarray(qdesc, np.uint8).reshape(-1, 32)
+    d3 = None if dir3d is None else np.ascontiguousarray(dir3d, np.float64).reshape(-1, 3)
+    tk = None if taken is None else np.ascontiguousarray(taken, np.uint8)
+    match = np.full(max(len(q), 1), -1, np.int32); asg = np.full(max(len(k), 1), -1, np.int32)
+    L.pso_line_search_by_projection.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int] + [C.c_float] * 4 + \
+        [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p]
+    n = L.pso_line_search_by_projection(_p(k), _p(d), _p(e), _p(d3), len(k), *bounds, _p(q), _p(qd), len(q), _p(tk), mode, nnratio, _p(match), _p(asg))
+    return n, match[:len(q)], asg[:len(k)]

@@ -73,3 +73,58 @@ def test_associate_planes(live):
     assert (assoc >= 0).sum() >= 1
     n, assoc = P.associate_planes(planes[:0], pts[:0], mp, 0.05, 0.999, live=live)
     assert n == 0
+
+
+def _line_queries(k0, rng, radius, th_cos, jitter=2.0, p_block=0.8):
+    import psl_slam_amd as P
+    q = np.zeros(len(k0), P.LINEQUERY_DTYPE)
+    for a, b in (("x1", "startPointX"), ("y1", "startPointY"), ("x2", "endPointX"), ("y2", "endPointY")):
+        q[a] = k0[b] + rng.uniform(-jitter, jitter, len(k0)).astype(np.float32)
+    q["radius"], q["th_cos"] = radius, th_cos
+    q["vx"] = k0["ePointInOctaveX"] - k0["sPointInOctaveX"]
+    q["vy"] = k0["ePointInOctaveY"] - k0["sPointInOctaveY"]
+    q["length"] = k0["lineLength"]
+    q["blocks"] = (rng.random(len(k0)) < p_block).astype(np.int32)
+    return q
+
+
+@pytest.mark.parametrize("style", ["struct", "desk"])
+def test_line_search_by_projection_last(style):
+    """LSDmatcher::SearchByProjection(cur,last,th) incl. mGridForLine (Bresenham) and GetFeaturesInAreaForLine."""
+    import psl_slam_amd as P
+    import oracle_lib
+    (k0, d0, _), (k1, d1, e1) = _two_frames(style)
+    rng = np.random.default_rng(7)
+    bounds = (0.0, 0.0, 640.0, 480.0)
+    q = _line_queries(k0, rng, 6.0, 0.96)
+    taken = (rng.random(len(k1)) < 0.1).astype(np.uint8)
+    nm, match, asg, gs, gi = P.LSDmatcher().SearchByProjection(k1, d1, e1, bounds, q, d0, mode=0, taken=taken, want_grid=True)
+    rgs, rgi = oracle_lib.line_grid_build(k1, bounds)
+    np.testing.assert_array_equal(gs, rgs)
+    np.testing.assert_array_equal(gi, rgi)
+    rnm, rmatch, rasg = oracle_lib.line_search_by_projection(k1, d1, e1, bounds, q, d0, 0, None, taken)
+    assert nm == rnm and nm > 5
+    np.testing.assert_array_equal(match, rmatch)
+    np.testing.assert_array_equal(asg, rasg)
+
+
+def test_line_search_by_projection_map():
+    """LSDmatcher::SearchByProjection(F, vpMapLines, ..): 3-D direction gate, best / second best ratio."""
+    import psl_slam_amd as P
+    import oracle_lib
+    (k0, d0, _), (k1, d1, e1) = _two_frames("struct")
+    rng = np.random.default_rng(9)
+    bounds = (0.0, 0.0, 640.0, 480.0)
+    q = _line_queries(k0, rng, 8.0, 0.998, jitter=1.0, p_block=1.0)
+    dir3d = rng.standard_normal((len(k1), 3))
+    # make most map-line normals agree with the frame line they should match (same index when it exists)
+    w = rng.standard_normal((len(k0), 3))
+    m = min(len(k0), len(k1))
+    w[:m] = dir3d[:m] + rng.normal(0, 0.05, (m, 3))
+    q["wdir"] = w
+    for ratio in (0.95, 0.7):
+        nm, match, asg = P.LSDmatcher(ratio).SearchByProjection(k1, d1, e1, bounds, q, d0, mode=1, dir3d=dir3d)
+        rnm, rmatch, rasg = oracle_lib.line_search_by_projection(k1, d1, e1, bounds, q, d0, 1, dir3d, None, ratio)
+        assert nm == rnm
+        np.testing.assert_array_equal(match, rmatch)
+        np.testing.assert_array_equal(asg, rasg)
