@@ -225,3 +225,22 @@ def test_line_extractor_empty_inputs():
     assert len(k) == 0 and d.shape == (0, 32)
     with pytest.raises(P.PslfeError):
         P.LINEextractor(2, 1.2, 200, 0.0)              # only numOctaves == 1 (every reference YAML)
+
+
+def test_hip_vs_committed_line_golden():
+    """HIP vs tests/golden/line_640x480_struct.npz: LSD segments, LBD on the golden keylines and pairing on the
+    golden lines are exact; the end-to-end extractor stays within the stated tolerance."""
+    import os
+    import psl_slam_amd as P
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "line_640x480_struct.npz"))
+    le = P.LINEextractor(1, 1.2, 200, 0.0)
+    seg = le.lsd_detect(g["image"])
+    np.testing.assert_array_equal(seg.view(np.uint32), g["segments"].view(np.uint32))
+    np.testing.assert_array_equal(le.lbd_compute(g["image"], g["kls"]), g["desc"])
+    L = np.stack([g["kls"][n] for n in ("startPointX", "startPointY", "endPointX", "endPointY")], 1).astype(np.float32)
+    np.testing.assert_array_equal(le.pair(L, 20.0, np.float32(np.pi / 4), 640, 480), g["fans"])
+    k, d, e = le(g["image"])
+    assert len(k) == len(g["kls"])
+    E = np.stack([k[n] for n in ("startPointX", "startPointY", "endPointX", "endPointY")], 1)
+    R = np.stack([g["kls"][n] for n in ("startPointX", "startPointY", "endPointX", "endPointY")], 1)
+    assert np.abs(E - R).max() <= 0.5

@@ -1,0 +1,96 @@
+"""Line-path oracle (oracle/line_oracle.cpp): definition-level checks, no GPU."""
+import ctypes as C
+import os
+
+import numpy as np
+
+import oracle_lib
+import synth_frames as sf
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def _edge_image():
+    img = np.full((240, 320), 60, np.uint8)
+    yy, xx = np.mgrid[0:240, 0:320]
+    img[yy > 0.5 * xx + 40] = 190          # one long straight edge: y = 0.5 x + 40
+    return img
+
+
+def test_lsd_finds_the_synthetic_edge():
+    seg = oracle_lib.lsd_detect(_edge_image())
+    assert len(seg) >= 1
+    L = np.hypot(seg[:, 2] - seg[:, 0], seg[:, 3] - seg[:, 1])
+    s = seg[L.argmax()]
+    assert L.max() > 250
+    for x, y in ((s[0], s[1]), (s[2], s[3])):      # both end points lie on the edge (within a pixel)
+        assert abs(y - (0.5 * x + 40)) < 1.5
+    assert len(oracle_lib.lsd_detect(np.full((240, 320), 99, np.uint8))) == 0
+
+
+def test_lsd_gradient_definition():
+    img = sf.Scene(160, 120, "struct", seed=2, n_poly=30).gray(0)
+    scaled, ang, mod = oracle_lib.lsd_gradient(img)
+    assert scaled.shape == (96, 128)
+    A, B, Cc, D = scaled[:-1, :-1], scaled[:-1, 1:], scaled[1:, :-1], scaled[1:, 1:]
+    gx, gy = (B + D) - (A + Cc), (Cc + D) - (A + B)
+    np.testing.assert_allclose(mod[:-1, :-1], np.sqrt((gx * gx + gy * gy) / 4.0), rtol=1e-12)
+    rho = 2.0 / np.sin(np.pi * 22.5 / 180)
+    defined = ang[:-1, :-1] != -1024.0
+    np.testing.assert_array_equal(defined, mod[:-1, :-1] > rho)
+    ref = np.mod(np.arctan2(gx, -gy), 2 * np.pi)     # level-line angle = atan2(gx, -gy)
+    d = np.abs(ang[:-1, :-1] - ref)[defined]
+    assert np.minimum(d, 2 * np.pi - d).max() < 0.006  # fastAtan2 is a 0.3-degree polynomial
+
+
+def test_line_iterator_count_and_clipping():
+    f = lambda *a: oracle_lib.load().pso_line_iterator_count(640, 480, *[C.c_float(v) for v in a])
+    assert f(10, 10, 110, 60) == 101
+    assert f(10.4, 10.5, 10.4, 10.5) == 1
+    assert f(-50, 100, 50, 100) == 51            # clipped at x = 0
+    assert f(600, 470, 700, 500) > 0 and f(700, 500, 800, 600) == 0
+
+
+def test_merge_two_collinear_segments():
+    seg = np.array([[10, 100, 110, 100.5], [118, 100.6, 260, 101.2], [300, 300, 340, 305]], np.float32)
+    kl = oracle_lib.optimize_and_merge(seg, 640, 480)
+    assert len(kl) == 1                          # the two collinear pieces merge, the 40-px one is filtered (< 50)
+    assert kl["startPointX"][0] < 12 and kl["endPointX"][0] > 258 and abs(kl["lineLength"][0] - 250) < 3
+    assert kl["class_id"][0] == 0 and kl["octave"][0] == 0
+    assert abs(kl["response"][0] - kl["lineLength"][0] / 640) < 1e-6
+
+
+def test_lbd_sobel_and_descriptor_basics():
+    img = _edge_image()
+    dx, dy = oracle_lib.lbd_sobel(img)
+    flat = np.full((50, 60), 90, np.uint8)
+    fx, fy = oracle_lib.lbd_sobel(flat)
+    assert (fx == 0).all() and (fy == 0).all()
+    assert dy[90, 100] > 0 and dx[90, 100] < 0     # at (x=100, y=90) on the edge: brighter below, darker to the right
+    seg = oracle_lib.lsd_detect(img)
+    kl = oracle_lib.optimize_and_merge(seg, 320, 240)
+    desc, fdesc = oracle_lib.lbd_compute(img, kl, want_float=True)
+    assert desc.shape == (len(kl), 32) and np.isfinite(fdesc).all()
+    np.testing.assert_allclose(np.linalg.norm(fdesc, axis=1), 1.0, atol=1e-5)   # re-normalised 72-vector
+    assert fdesc.max() <= 0.4 / 0.4 + 1e-6
+
+
+def test_pairing_right_angle_corner():
+    lines = np.array([[100, 100, 200, 100], [205, 105, 205, 200], [100, 300, 200, 300]], np.float32)
+    fans = oracle_lib.lil_pair(lines, 20.0, np.float32(np.pi / 4), 640, 480)
+    assert len(fans) == 1 and {int(fans[0, 2]), int(fans[0, 3])} == {0, 1}
+    assert abs(fans[0, 0] - 205) < 1e-3 and abs(fans[0, 1] - 100) < 1e-3     # intersection of the two supports
+    par = np.array([[100, 100, 200, 100], [205, 104, 300, 104]], np.float32)     # near-parallel: rejected by fanThr
+    assert len(oracle_lib.lil_pair(par, 20.0, np.float32(np.pi / 4), 640, 480)) == 0
+
+
+def test_line_golden_vectors():
+    g = np.load(os.path.join(GOLD, "line_640x480_struct.npz"))
+    kls, desc, eq = oracle_lib.line_extract(g["image"], 200)
+    assert kls.tobytes() == g["kls"].tobytes()
+    np.testing.assert_array_equal(desc, g["desc"])
+    np.testing.assert_array_equal(eq, g["eq"])
+    np.testing.assert_array_equal(oracle_lib.lsd_detect(g["image"]), g["segments"])
+    L = np.stack([kls[n] for n in ("startPointX", "startPointY", "endPointX", "endPointY")], 1).astype(np.float32)
+    np.testing.assert_array_equal(oracle_lib.lil_pair(L, 20.0, np.float32(np.pi / 4), 640, 480), g["fans"])

@@ -87,3 +87,54 @@ def test_search_by_projection_sequential_semantics_small():
         nm, match, assigned = oracle_lib.search_by_projection_last(kps, desc, None, BOUNDS, q, qd, None, False)
         assert list(match) == exp and nm == 2
         assert assigned[0] == (0 if blocks else 1)
+
+
+def test_frame_bf_match_against_numpy():
+    """FrameBFMatch + lineDescriptorMAD (add_src/LSDmatcher.cpp:492-516, 660-685) re-derived in numpy."""
+    rng = np.random.default_rng(3)
+    t = rng.integers(0, 256, (120, 32), dtype=np.uint8)
+    q = t[rng.integers(0, 120, 100)].copy()
+    q[:, :4] ^= rng.integers(0, 256, (100, 4), dtype=np.uint8)
+    idx, dist = oracle_lib.hamming_knn2(q, t)
+    d0, d1 = dist[:, 0].astype(np.float32), dist[:, 1].astype(np.float32)
+    gap = d1 - d0
+    med = np.sort(gap)[len(gap) // 2]
+    mad = 1.4826 * np.sort(np.abs(gap - med))[len(gap) // 2]
+    for ratio, TH in ((0.95, 80.0), (0.8, 40.0)):
+        exp = np.where((gap > mad * 0.5) & (d0 < TH) & (d0 < np.float32(ratio) * d1), idx[:, 0], -1)
+        np.testing.assert_array_equal(oracle_lib.frame_bf_match(q, t, ratio, TH), exp)
+
+
+def test_associate_planes_running_threshold():
+    """The live variant (src/Map.cc:249-251) overwrites dTh with the signed distance: once a negative
+    distance is accepted nothing can be associated any more; the dead variant keeps a per-plane copy."""
+    planes = np.array([[0, 0, 1, -1.0], [0, 0, 1, -1.0]], np.float32)
+    pts = np.zeros((2, 5, 3))
+    pts[0, :, 2] = 0.99   # 0.99 - 1 = -0.01 -> dis = -0.01
+    pts[1, :, 2] = 1.02   # dis = +0.02
+    mp = np.array([[0, 0, 1, -1.0]], np.float32)
+    n, assoc = oracle_lib.associate_planes(planes, pts, mp, 0.05, 0.999, True)
+    assert n == 1 and list(assoc) == [0, -1]          # dTh became -0.01 after the first association
+    n, assoc = oracle_lib.associate_planes(planes, pts, mp, 0.05, 0.999, False)
+    assert n == 2 and list(assoc) == [0, 0]
+
+
+def test_line_grid_and_area_small():
+    """mGridForLine via the Bresenham iterator: a horizontal line crosses one row of cells, and a probe
+    next to it finds it (GetFeaturesInAreaForLine) while a perpendicular query line does not (cos gate)."""
+    kl = np.zeros(1, oracle_lib.KEYLINE_DTYPE)
+    kl["startPointX"], kl["startPointY"], kl["endPointX"], kl["endPointY"] = 105.0, 205.0, 305.0, 205.0
+    for a, b in (("sPointInOctaveX", "startPointX"), ("sPointInOctaveY", "startPointY"), ("ePointInOctaveX", "endPointX"), ("ePointInOctaveY", "endPointY")):
+        kl[a] = kl[b]
+    kl["lineLength"] = 200.0
+    bounds = (0.0, 0.0, 640.0, 480.0)
+    start, idx = oracle_lib.line_grid_build(kl, bounds)
+    cells = [c for c in range(64 * 48) if start[c + 1] > start[c]]
+    assert [c // 48 for c in cells] == list(range(10, 31)) and {c % 48 for c in cells} == {20}
+    eq = np.array([[0.0, 1.0, -205.0]])
+    desc = np.zeros((1, 32), np.uint8)
+    q = np.zeros(2, oracle_lib.LINEQUERY_DTYPE)
+    q["x1"], q["y1"], q["x2"], q["y2"] = [100, 200], [207, 100], [300, 200], [207, 300]
+    q["radius"], q["th_cos"], q["vx"], q["vy"], q["length"], q["blocks"] = 6.0, 0.96, [200, 0], [0, 200], 200.0, 1
+    n, match, asg = oracle_lib.line_search_by_projection(kl, desc, eq, bounds, q, np.zeros((2, 32), np.uint8), 0)
+    assert n == 1 and list(match) == [0, -1] and list(asg) == [0]
