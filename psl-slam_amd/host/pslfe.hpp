@@ -141,6 +141,55 @@ public:
     bool mbCheckOrientation;
 };
 
+// == ORB_SLAM2::LINEextractor (add_inc/LineExtractor.h:160-255)
+class LINEextractor {
+public:
+    LINEextractor(Context& ctx, int numOctaves, float scale, unsigned int nLSDFeature, double min_line_length, int maxBatch = 1)
+        : numOctaves_(numOctaves) {
+        check(pslfe_line_create(ctx.get(), numOctaves, scale, (int)nLSDFeature, min_line_length, maxBatch, &h_), "pslfe_line_create");
+    }
+    ~LINEextractor() { pslfe_line_destroy(h_); }
+    LINEextractor(const LINEextractor&) = delete;
+    LINEextractor& operator=(const LINEextractor&) = delete;
+
+    // operator()(image, mask, keylines, descriptors, lineVec2d): empty image leaves the outputs untouched
+    // (add_src/LineExtractor.cpp:327); lineVec2d holds 3 doubles per line (Eigen::Vector3d layout).
+    void operator()(const uint8_t* image, int cols, int rows, int step, std::vector<PslKeyLine>& keylines, std::vector<uint8_t>& descriptors,
+                    std::vector<double>& lineVec2d) {
+        if (!image || cols <= 0 || rows <= 0) return;
+        const int cap = 2048;
+        keylines.resize(cap); descriptors.resize((size_t)cap * 32); lineVec2d.resize((size_t)cap * 3);
+        int n = 0;
+        check(pslfe_line_extract(h_, image, cols, rows, step, keylines.data(), descriptors.data(), lineVec2d.data(), cap, &n), "pslfe_line_extract");
+        keylines.resize(n); descriptors.resize((size_t)n * 32); lineVec2d.resize((size_t)n * 3);
+    }
+    // CPartiallyRecoverConnectivity(mLines, radius, fans, img, fanThr): mLines n x 4 floats, fans k x 4
+    void PartiallyRecoverConnectivity(const std::vector<float>& mLines, float radius, std::vector<float>& fans, int imgCols, int imgRows, float fanThr) {
+        const int n = (int)mLines.size() / 4, cap = 4096;
+        fans.resize((size_t)cap * 4);
+        int k = 0;
+        check(pslfe_lil_pair(h_, mLines.data(), n, radius, fanThr, imgCols, imgRows, fans.data(), cap, &k), "pslfe_lil_pair");
+        fans.resize((size_t)k * 4);
+    }
+    int GetLevels() const { return pslfe_line_levels(h_); }
+    float GetScaleFactor() const { return pslfe_line_scale_factor(h_); }
+    std::vector<float> GetScaleFactors() const { return factors(0); }
+    std::vector<float> GetInverseScaleFactors() const { return factors(1); }
+    std::vector<float> GetScaleSigmaSquares() const { return factors(2); }
+    std::vector<float> GetInverseScaleSigmaSquares() const { return factors(3); }
+    pslfe_line* get() const { return h_; }
+
+private:
+    std::vector<float> factors(int which) const {
+        std::vector<float> v[4];
+        for (auto& x : v) x.resize(numOctaves_);
+        check(pslfe_line_scale_factors(h_, v[0].data(), v[1].data(), v[2].data(), v[3].data()), "pslfe_line_scale_factors");
+        return v[which];
+    }
+    pslfe_line* h_ = nullptr;
+    int numOctaves_;
+};
+
 class LSDmatcher {
 public:
     static const int TH_HIGH = 80, TH_LOW = 50;  // add_src/LSDmatcher.cpp:12-14
@@ -154,6 +203,39 @@ public:
         return nm;
     }
     int match(const std::vector<uint8_t>& d1, const std::vector<uint8_t>& d2, float nnr, std::vector<int>& m12) { return matchNNR(d1, d2, nnr, m12); }
+    // SearchByGeomNApearance(CurrentFrame, LastFrame, desc_th), add_src/LSDmatcher.cpp:36-110: assigned[i2] = last-frame line
+    // whose map line CurrentFrame.mvpMapLines[i2] receives
+    int SearchByGeomNApearance(const std::vector<PslKeyLine>& klLast, const std::vector<uint8_t>& descLast, const std::vector<PslKeyLine>& klCur,
+                               const std::vector<uint8_t>& descCur, const std::vector<uint8_t>& lastHasMapLine, float desc_th, float mnMinX,
+                               float mnMaxX, float mnMinY, float mnMaxY, std::vector<int32_t>& matches_12, std::vector<int32_t>& assigned) {
+        matches_12.assign(klLast.size(), -1);
+        assigned.assign(klCur.size(), -1);
+        int n = 0;
+        check(pslfe_line_search_by_geom_appearance(ctx_.get(), klLast.data(), descLast.data(), (int)klLast.size(), klCur.data(), descCur.data(),
+                                                   (int)klCur.size(), lastHasMapLine.data(), desc_th, mnMinX, mnMaxX, mnMinY, mnMaxY,
+                                                   matches_12.data(), assigned.data(), &n), "pslfe_line_search_by_geom_appearance");
+        return n;
+    }
+    // FrameBFMatch(ldesc1, ldesc2, LineMatches, TH), add_src/LSDmatcher.cpp:492-516
+    void FrameBFMatch(const std::vector<uint8_t>& ldesc1, const std::vector<uint8_t>& ldesc2, std::vector<int>& LineMatches, float TH) {
+        LineMatches.assign(ldesc1.size() / 32, -1);
+        check(pslfe_line_frame_bf_match(ctx_.get(), ldesc1.data(), (int)ldesc1.size() / 32, ldesc2.data(), (int)ldesc2.size() / 32, mfNNratio, TH,
+                                        LineMatches.data()), "pslfe_line_frame_bf_match");
+    }
+    // SearchByProjection(CurrentFrame, LastFrame, th) :112-215 (mode 0) / SearchByProjection(F, vpMapLines, eval_orient, th) :260-352 (mode 1)
+    int SearchByProjection(const std::vector<PslKeyLine>& kls, const std::vector<uint8_t>& ldesc, const std::vector<double>& keyLineFunctions,
+                           const double* lines3dDir, float mnMinX, float mnMinY, float mnMaxX, float mnMaxY, const std::vector<PslLineQuery>& queries,
+                           const std::vector<uint8_t>& qdesc, const uint8_t* taken, int mode, std::vector<int32_t>& match,
+                           std::vector<int32_t>* assigned = nullptr) {
+        match.assign(queries.size(), -1);
+        if (assigned) assigned->assign(kls.size(), -1);
+        int n = 0;
+        check(pslfe_line_search_by_projection(ctx_.get(), kls.data(), ldesc.data(), keyLineFunctions.data(), lines3dDir, (int)kls.size(), mnMinX,
+                                              mnMinY, mnMaxX, mnMaxY, queries.data(), qdesc.data(), (int)queries.size(), taken, mode, mfNNratio,
+                                              match.data(), assigned ? assigned->data() : nullptr, &n, nullptr, nullptr, 0, nullptr),
+              "pslfe_line_search_by_projection");
+        return n;
+    }
 private:
     Context& ctx_;
 public:
