@@ -440,7 +440,8 @@ struct LsdW {
     const float* ang;
     const double* mod;
     const float4* trig;
-    uint32_t* used;   // LDS bitmap
+    uint32_t* used;   // bitmap: LDS (k_lsd_grow2) or HBM (k_lsd_grow3, gused = true)
+    bool gused;
     uint32_t* ring;   // LDS mirror of reg[idx & (RING-1)]
     double* term;     // LDS [3][64]
     uint32_t* reg;    // HBM queue
@@ -474,26 +475,46 @@ __device__ int lsdw_region_grow(const LsdW& F, int sx, int sy, double* reg_angle
     float sumdx = t0.z, sumdy = t0.w;  // float(cos(reg_angle)), float(sin(reg_angle))
     lsdw_set(F, addr0);
     const int e = F.lane / 9, k = F.lane - e * 9, ky = k / 3, kx = k - ky * 3;
+    // neighbour data of the entries popped in this round (cur) and, software-pipelined, of the entries the
+    // NEXT round will pop if they are already queued (nxt): their loads fly while this round's chain runs
+    float a_n = PSL_LSD_NOTDEF, cs_n = 0.f, sn_n = 0.f;
+    uint32_t xy_n = 0;
+    int pre = 0;
     int i = 0;
     while (i < reg_size) {
         const int nb = min(7, reg_size - i);
-        const bool act = F.lane < 63 && e < nb;
-        int c = 0, nx = 0, ny = 0;
-        float a = PSL_LSD_NOTDEF;
-        float sn = 0.f, cs = 0.f;
-        if (act) {
-            const uint32_t rp = lsdw_reg(F, i + e, reg_size);
-            nx = (int)(rp & 0xffff) + kx - 1;
-            ny = (int)(rp >> 16) + ky - 1;
+        float a = PSL_LSD_NOTDEF, sn = 0.f, cs = 0.f;
+        uint32_t xy = 0;  // nx | ny << 16
+        if (F.lane < 63 && e < nb) {
+            if (e < pre) { a = a_n; cs = cs_n; sn = sn_n; xy = xy_n; }
+            else {
+                const uint32_t rp = lsdw_reg(F, i + e, reg_size);
+                const int nx = (int)(rp & 0xffff) + kx - 1, ny = (int)(rp >> 16) + ky - 1;
+                if (nx >= 0 && nx < F.W && ny >= 0 && ny < F.H) {
+                    const int c = nx + ny * F.W;
+                    a = F.ang[c];
+                    const float2 t = *reinterpret_cast<const float2*>(&F.trig[c]);  // cosf, sinf of this pixel's angle
+                    cs = t.x; sn = t.y;
+                    xy = (uint32_t)nx | ((uint32_t)ny << 16);
+                }
+            }
+        }
+        pre = min(7, reg_size - (i + nb));
+        a_n = PSL_LSD_NOTDEF;
+        if (F.lane < 63 && e < pre) {
+            const uint32_t rp = lsdw_reg(F, i + nb + e, reg_size);
+            const int nx = (int)(rp & 0xffff) + kx - 1, ny = (int)(rp >> 16) + ky - 1;
             if (nx >= 0 && nx < F.W && ny >= 0 && ny < F.H) {
-                c = nx + ny * F.W;
-                a = F.ang[c];
-                const float2 t = *reinterpret_cast<const float2*>(&F.trig[c]);  // cosf, sinf of this pixel's angle
-                cs = t.x; sn = t.y;
+                const int c = nx + ny * F.W;
+                a_n = F.ang[c];
+                const float2 t = *reinterpret_cast<const float2*>(&F.trig[c]);
+                cs_n = t.x; sn_n = t.y;
+                xy_n = (uint32_t)nx | ((uint32_t)ny << 16);
             }
         }
         const bool cand0 = a != PSL_LSD_NOTDEF;
         const double ad = PSL_DMUL((double)a, PSL_DEG2RAD);
+        const int c = (int)(xy & 0xffff) + (int)(xy >> 16) * F.W;
         // lanes are ordered (entry, neighbour) exactly as the reference visits them, so one cursor over the
         // lane index replaces the per-entry loops: take the first lane >= cursor that is still unused and
         // aligned with the CURRENT angle, add it, move the cursor behind it, re-test the rest.
@@ -502,11 +523,12 @@ __device__ int lsdw_region_grow(const LsdW& F, int sx, int sy, double* reg_angle
             const bool ok = cand0 && F.lane >= cursor && !lsdw_used(F, c) && lsdw_aligned(ad, reg_angle, prec);
             const unsigned long long m = __ballot(ok);
             if (!m) break;
-            const int L = __ffsll((long long)m) - 1;
-            const int cL = __shfl(c, L), xL = __shfl(nx, L), yL = __shfl(ny, L);
-            const float csL = __shfl(cs, L), snL = __shfl(sn, L);
-            lsdw_set(F, cL);
-            lsdw_push(F, reg_size, (uint32_t)xL | ((uint32_t)yL << 16));
+            const int L = __ffsll((long long)m) - 1;  // wave-uniform: v_readlane instead of ds_bpermute
+            const uint32_t xyL = (uint32_t)__builtin_amdgcn_readlane((int)xy, L);
+            const float csL = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cs), L));
+            const float snL = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sn), L));
+            lsdw_set(F, (int)(xyL & 0xffff) + (int)(xyL >> 16) * F.W);
+            lsdw_push(F, reg_size, xyL);
             ++reg_size;
             sumdx = PSL_FADD(sumdx, csL);
             sumdy = PSL_FADD(sumdy, snL);
@@ -515,6 +537,96 @@ __device__ int lsdw_region_grow(const LsdW& F, int sx, int sy, double* reg_angle
         }
         i += nb;
     }
+    *reg_angle_out = reg_angle;
+    return reg_size;
+}
+
+// ---- variant with the `used` bitmap in HBM (L2-resident: 24 KB per frame) --------------------------
+// Frees the 24 KB of LDS per wave, so 4-5 waves per SIMD can overlap their serial chains.  The bitmap is
+// written with agent-scope atomics (lane 0) and read with agent-scope relaxed loads (L1 bypass); inside a
+// round every lane keeps its own "used" flag, updated by comparing its pixel with each pixel that is added.
+__device__ __forceinline__ uint32_t lsdg_word(const LsdW& F, int w) {
+    return __hip_atomic_load(&F.used[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ bool lsdg_used(const LsdW& F, int a) { return (lsdg_word(F, a >> 5) >> (a & 31)) & 1u; }
+__device__ __forceinline__ void lsdg_set(const LsdW& F, int a) {
+    if (F.lane == 0) __hip_atomic_fetch_or(&F.used[a >> 5], 1u << (a & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ int lsdg_region_grow(const LsdW& F, int sx, int sy, double* reg_angle_out, double prec) {
+    int reg_size = 1;
+    const int addr0 = sx + sy * F.W;
+    lsdw_push(F, 0, (uint32_t)sx | ((uint32_t)sy << 16));
+    double reg_angle = PSL_DMUL((double)F.ang[addr0], PSL_DEG2RAD);
+    const float4 t0 = F.trig[addr0];
+    float sumdx = t0.z, sumdy = t0.w;
+    lsdg_set(F, addr0);
+    const int e = F.lane / 9, k = F.lane - e * 9, ky = k / 3, kx = k - ky * 3;
+    float a_n = PSL_LSD_NOTDEF, cs_n = 0.f, sn_n = 0.f;
+    uint32_t xy_n = 0;
+    bool u_n = true;
+    int pre = 0;
+    int i = 0;
+    while (i < reg_size) {
+        const int nb = min(7, reg_size - i);
+        // every bitmap update and every prefetch issued so far must have landed before this round reads
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        float a = PSL_LSD_NOTDEF, sn = 0.f, cs = 0.f;
+        uint32_t xy = 0;
+        bool u = true;
+        if (F.lane < 63 && e < nb) {
+            if (e < pre) { a = a_n; cs = cs_n; sn = sn_n; xy = xy_n; u = u_n; }
+            else {
+                const uint32_t rp = lsdw_reg(F, i + e, reg_size);
+                const int nx = (int)(rp & 0xffff) + kx - 1, ny = (int)(rp >> 16) + ky - 1;
+                if (nx >= 0 && nx < F.W && ny >= 0 && ny < F.H) {
+                    const int c = nx + ny * F.W;
+                    a = F.ang[c];
+                    const float2 t = *reinterpret_cast<const float2*>(&F.trig[c]);
+                    cs = t.x; sn = t.y;
+                    xy = (uint32_t)nx | ((uint32_t)ny << 16);
+                    u = lsdg_used(F, c);
+                }
+            }
+        }
+        pre = min(7, reg_size - (i + nb));
+        a_n = PSL_LSD_NOTDEF; u_n = true;
+        if (F.lane < 63 && e < pre) {
+            const uint32_t rp = lsdw_reg(F, i + nb + e, reg_size);
+            const int nx = (int)(rp & 0xffff) + kx - 1, ny = (int)(rp >> 16) + ky - 1;
+            if (nx >= 0 && nx < F.W && ny >= 0 && ny < F.H) {
+                const int c = nx + ny * F.W;
+                a_n = F.ang[c];
+                const float2 t = *reinterpret_cast<const float2*>(&F.trig[c]);
+                cs_n = t.x; sn_n = t.y;
+                xy_n = (uint32_t)nx | ((uint32_t)ny << 16);
+                u_n = lsdg_used(F, c);
+            }
+        }
+        const bool cand0 = a != PSL_LSD_NOTDEF;
+        const double ad = PSL_DMUL((double)a, PSL_DEG2RAD);
+        int cursor = 0;
+        while (true) {
+            const bool ok = cand0 && F.lane >= cursor && !u && lsdw_aligned(ad, reg_angle, prec);
+            const unsigned long long m = __ballot(ok);
+            if (!m) break;
+            const int L = __ffsll((long long)m) - 1;
+            const uint32_t xyL = (uint32_t)__builtin_amdgcn_readlane((int)xy, L);
+            const float csL = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cs), L));
+            const float snL = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sn), L));
+            if (cand0 && xy == xyL) u = true;                          // duplicates of this pixel in the current round
+            if (a_n != PSL_LSD_NOTDEF && xy_n == xyL) u_n = true;      // ... and in the prefetched next round
+            lsdg_set(F, (int)(xyL & 0xffff) + (int)(xyL >> 16) * F.W);
+            lsdw_push(F, reg_size, xyL);
+            ++reg_size;
+            sumdx = PSL_FADD(sumdx, csL);
+            sumdy = PSL_FADD(sumdy, snL);
+            reg_angle = PSL_DMUL((double)psl_fast_atan2(sumdy, sumdx), PSL_DEG2RAD);
+            cursor = L + 1;
+        }
+        i += nb;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     *reg_angle_out = reg_angle;
     return reg_size;
 }
@@ -615,7 +727,7 @@ __device__ int lsdw_refine(const LsdW& F, int reg_size, double reg_angle, double
     }
     const double mean_angle = sum / (double)n;
     const double tau = PSL_DMUL(2.0, __dsqrt_rn(PSL_DADD(PSL_DSUB(s_sum, PSL_DMUL(PSL_DMUL(2.0, mean_angle), sum)) / (double)n, PSL_DMUL(mean_angle, mean_angle))));
-    reg_size = lsdw_region_grow(F, x0, y0, &reg_angle, tau);
+    reg_size = F.gused ? lsdg_region_grow(F, x0, y0, &reg_angle, tau) : lsdw_region_grow(F, x0, y0, &reg_angle, tau);
     if (reg_size < 2) return 0;
     lsdw_region2rect(F, reg_size, reg_angle, prec, rec);
     density = psl_lsd_density(reg_size, *rec);
@@ -634,7 +746,7 @@ __device__ int lsdw_refine(const LsdW& F, int reg_size, double reg_angle, double
             if (psl_dist_sq(xc, yc, (double)px, (double)py) > radSq) {
                 const int a = px + py * F.W;
                 const uint32_t last = F.reg[reg_size - 1];
-                if (F.lane == 0) { F.used[a >> 5] &= ~(1u << (a & 31)); F.reg[i] = last; F.reg[reg_size - 1] = rp; }
+                if (F.lane == 0) { atomicAnd(&F.used[a >> 5], ~(1u << (a & 31))); F.reg[i] = last; F.reg[reg_size - 1] = rp; }
                 __builtin_amdgcn_wave_barrier();
                 --reg_size;
                 --i;
@@ -664,7 +776,7 @@ __global__ __launch_bounds__(64) void k_lsd_grow2(LineParams P, const float* __r
     LsdW F;
     F.W = P.W; F.H = P.H; F.lane = lane;
     F.ang = angdeg + frame * npx; F.mod = modgrad + frame * npx; F.trig = trig + frame * npx; F.reg = reg + frame * npx;
-    F.used = s_dyn; F.ring = s_ring; F.term = s_term;
+    F.used = s_dyn; F.gused = false; F.ring = s_ring; F.term = s_term;
     for (int i = lane; i < words; i += 64) F.used[i] = 0;
     __builtin_amdgcn_wave_barrier();
     float* out = seg + (size_t)frame * P.maxseg * 4;
@@ -706,6 +818,74 @@ __global__ __launch_bounds__(64) void k_lsd_grow2(LineParams P, const float* __r
                 ++count;
             }
             (void)ad;
+        }
+    }
+    if (lane == 0) nseg[frame] = count < P.maxseg ? count : P.maxseg;
+}
+
+
+__global__ __launch_bounds__(64) void k_lsd_grow3(LineParams P, const float* __restrict__ angdeg, const double* __restrict__ modgrad,
+                                                   const float4* __restrict__ trig, uint32_t* __restrict__ usedbits, uint32_t* __restrict__ reg,
+                                                   float* __restrict__ seg, int* __restrict__ nseg) {
+    __shared__ uint32_t s_ring[PSL_LSD_RING];
+    __shared__ double s_term[3 * 64];
+    const int frame = blockIdx.x, lane = threadIdx.x;
+    const size_t npx = (size_t)P.W * P.H;
+    const int words = (int)((npx + 31) >> 5);
+    LsdW F;
+    F.W = P.W; F.H = P.H; F.lane = lane;
+    F.ang = angdeg + frame * npx; F.mod = modgrad + frame * npx; F.trig = trig + frame * npx; F.reg = reg + frame * npx;
+    F.used = usedbits + (size_t)frame * words; F.gused = true; F.ring = s_ring; F.term = s_term;
+    for (int i = lane; i < words; i += 64) __hip_atomic_store(&F.used[i], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    float* out = seg + (size_t)frame * P.maxseg * 4;
+    int count = 0;
+    const int scan_end = (P.H - 1) * P.W;
+    for (int base = 0; base < scan_end; base += 256) {
+        float a4[4];
+        uint32_t u4[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int ad = base + q * 64 + lane;
+            a4[q] = ad < scan_end ? F.ang[ad] : PSL_LSD_NOTDEF;
+            u4[q] = ad < scan_end ? lsdg_word(F, ad >> 5) : 0xffffffffu;
+        }
+        bool grown = false;  // a region was grown since the used words of this chunk were loaded
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int ad = base + q * 64 + lane;
+            unsigned long long mask = __ballot(a4[q] != PSL_LSD_NOTDEF && !((u4[q] >> (ad & 31)) & 1u));
+            while (mask) {
+                const int s = __ffsll((long long)mask) - 1;
+                mask &= mask - 1;
+                const int adx = base + q * 64 + s;
+                if (grown) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if (lsdg_used(F, adx)) continue;
+                }
+                const int y = adx / P.W, x = adx - y * P.W;
+                double reg_angle;
+                int reg_size = lsdg_region_grow(F, x, y, &reg_angle, P.prec);
+                grown = true;
+                if (reg_size < P.min_reg_size) continue;
+                LsdRect rec;
+                lsdw_region2rect(F, reg_size, reg_angle, P.prec, &rec);
+                if (!lsdw_refine(F, reg_size, reg_angle, P.prec, &rec, 0.7)) continue;
+                if (count < P.maxseg && lane == 0) {
+                    float e[4] = {(float)(PSL_DADD(rec.x1, 0.5) / 0.8), (float)(PSL_DADD(rec.y1, 0.5) / 0.8),
+                                  (float)(PSL_DADD(rec.x2, 0.5) / 0.8), (float)(PSL_DADD(rec.y2, 0.5) / 0.8)};
+                    if (e[0] < 0) e[0] = 0;
+                    if (e[0] >= P.w) e[0] = (float)P.w - 1.0f;
+                    if (e[2] < 0) e[2] = 0;
+                    if (e[2] >= P.w) e[2] = (float)P.w - 1.0f;
+                    if (e[1] < 0) e[1] = 0;
+                    if (e[1] >= P.h) e[1] = (float)P.h - 1.0f;
+                    if (e[3] < 0) e[3] = 0;
+                    if (e[3] >= P.h) e[3] = (float)P.h - 1.0f;
+                    out[4 * count] = e[0]; out[4 * count + 1] = e[1]; out[4 * count + 2] = e[2]; out[4 * count + 3] = e[3];
+                }
+                ++count;
+            }
         }
     }
     if (lane == 0) nseg[frame] = count < P.maxseg ? count : P.maxseg;

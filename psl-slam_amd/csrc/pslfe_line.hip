@@ -29,6 +29,7 @@ struct pslfe_line {
     double* d_modgrad = nullptr;
     float4* d_trig = nullptr;
     uint8_t* d_used = nullptr;
+    uint32_t* d_usedbits = nullptr;
     uint32_t* d_reg = nullptr;
     float* d_seg = nullptr;
     int* d_nseg = nullptr;
@@ -56,6 +57,7 @@ struct pslfe_line {
         d_kls = nullptr; d_ldesc = nullptr; d_fdesc = nullptr; d_lineEq = nullptr; d_nkl = nullptr; d_status = nullptr; d_lbdblur = nullptr;
         d_dx = nullptr; d_dy = nullptr; d_rawfans = nullptr; d_fans = nullptr; d_nfans = nullptr; d_tmplines = nullptr;
         hipFree(d_trig); d_trig = nullptr;
+        hipFree(d_usedbits); d_usedbits = nullptr;
         hipFree(d_in); hipFree(d_scaled); hipFree(d_angdeg); hipFree(d_modgrad); hipFree(d_used); hipFree(d_reg);
         hipFree(d_seg); hipFree(d_nseg);
         d_in = nullptr; d_scaled = nullptr; d_angdeg = nullptr; d_modgrad = nullptr; d_used = nullptr; d_reg = nullptr;
@@ -114,6 +116,7 @@ struct pslfe_line {
         PSL_HIP(hipMalloc((void**)&d_modgrad, npx * F * sizeof(double)));
         PSL_HIP(hipMalloc((void**)&d_trig, npx * F * sizeof(float4)));
         PSL_HIP(hipMalloc((void**)&d_used, npx * F));
+        PSL_HIP(hipMalloc((void**)&d_usedbits, ((npx + 31) / 32) * sizeof(uint32_t) * F));
         PSL_HIP(hipMalloc((void**)&d_reg, npx * F * sizeof(uint32_t)));
         PSL_HIP(hipMalloc((void**)&d_seg, (size_t)Q.maxseg * 4 * sizeof(float) * F));
         PSL_HIP(hipMalloc((void**)&d_nseg, F * sizeof(int)));
@@ -174,7 +177,10 @@ struct pslfe_line {
         {
             PSL_STAGE_BEGIN(ctx, "line.lsd_grow");
             const size_t lds = (((size_t)P.W * P.H + 31) / 32) * sizeof(uint32_t);
-            if (lds <= 140 * 1024 && !getenv("PSLFE_LSD_SERIAL")) {
+            const char* variant = getenv("PSLFE_LSD_GROW");  // "serial" | "lds" | default: HBM bitmap, many waves per SIMD
+            if (!variant || (strcmp(variant, "serial") != 0 && strcmp(variant, "lds") != 0)) {
+                k_lsd_grow3<<<F, 64, 0, st>>>(P, d_angdeg, d_modgrad, d_trig, d_usedbits, d_reg, d_seg, d_nseg);
+            } else if (lds <= 140 * 1024 && strcmp(variant, "lds") == 0) {
                 if (lds > 48 * 1024) PSL_HIP(hipFuncSetAttribute((const void*)k_lsd_grow2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 k_lsd_grow2<<<F, 64, lds, st>>>(P, d_angdeg, d_modgrad, d_trig, d_reg, d_seg, d_nseg);
             } else {

@@ -59,6 +59,26 @@ def test_lsd_segments(style, seed):
     assert frac >= 0.95 and abs(len(got) - len(ref)) <= 0.05 * len(ref)
 
 
+def test_lsd_large_regions_exercise_queue_overflow():
+    """Wide smooth ramps give regions of several thousand pixels (> the 1024-entry LDS ring of the queue),
+    thick bars give regions that fail the density test and go through refine / reduce_region_radius."""
+    import psl_slam_amd as P
+    import oracle_lib
+    yy, xx = np.mgrid[0:480, 0:640]
+    img = np.clip(40 + 0.9 * (xx - 100) * (xx > 100) * (xx < 300) + 180 * (xx >= 300), 0, 255)
+    img = np.where(yy > 300, np.clip(30 + 1.2 * (yy - 300), 0, 255), img)
+    img[100:140, 350:600] = 20
+    img[180:190, 340:620] = 240
+    rng = np.random.default_rng(5)
+    img = np.clip(img + rng.normal(0, 1.0, img.shape), 0, 255).astype(np.uint8)
+    got = P.LINEextractor().lsd_detect(img)
+    ref = oracle_lib.lsd_detect(img)
+    exact = got.shape == ref.shape and (got.view(np.uint32) == ref.view(np.uint32)).all()
+    print(f"LSD ramps: {len(got)} vs oracle {len(ref)} segments, bit-identical {exact}")
+    assert len(ref) >= 4 and _match_segments(got, ref) >= 0.95 and abs(len(got) - len(ref)) <= max(1, 0.05 * len(ref))
+    assert exact
+
+
 def test_lsd_flat_image_gives_no_segments():
     import psl_slam_amd as P
     assert len(P.LINEextractor().lsd_detect(np.full((480, 640), 128, np.uint8))) == 0
