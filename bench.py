@@ -126,7 +126,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=0, help="frames per step per GPU (default 256; 1024 for --workload lines)")
+    ap.add_argument("--batch", type=int, default=0, help="frames per step per GPU (default 256; 4096 for --workload lines)")
     ap.add_argument("--workload", choices=["orb", "lines"], default="orb",
                     help="orb = BASELINE configs[1] (ORB extract+match); lines = configs[2] (ORB + LSD/LBD + pairing, extract+match)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -149,7 +149,7 @@ def main():
     multigpu = import_module("psl_slam_amd.multigpu")
     P.build()
     LINES = args.workload == "lines"
-    B = args.batch or (1024 if LINES else 256)
+    B = args.batch or (4096 if LINES else 256)
     frames_h = synth_batch(B, P_seed(rank), style="struct" if LINES else "desk")
     frames_d = torch.from_numpy(frames_h).to(dev)
 

@@ -352,41 +352,56 @@ __global__ __launch_bounds__(256) void k_line_merge(LineParams P, MergeScratch M
 // LBD pre-processing (binary_descriptor_custom.cpp:351-399): GaussianBlur 5x5 sigma 1 on 8U (integer
 // kernel, sum 257) then Sobel 3x3 -> s16 dx, dy, both BORDER_REFLECT_101.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_lbd_blur5(LineParams P, const uint8_t* __restrict__ gray, int stride, size_t fstride,
-                                                    uint8_t* __restrict__ blur) {
-    const int frame = blockIdx.z;
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= P.w || y >= P.h) return;
+// Fused and tiled: a 64 x 32 output tile needs 66 x 34 blurred samples, i.e. 70 x 38 input pixels staged in
+// LDS.  Blur values in the 1-px halo of the image border are computed from reflected input, which equals
+// reflecting the blurred image because the kernel is symmetric.  Output: interleaved (dx, dy) as short2.
+__global__ __launch_bounds__(256) void k_lbd_pre(LineParams P, const uint8_t* __restrict__ gray, int stride, size_t fstride,
+                                                  short2* __restrict__ dxy) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_in[38 * 72];
+    __shared__ uint16_t s_row[38 * 68];
+    __shared__ uint8_t s_bl[34 * 68];
+    const int frame = blockIdx.z, tid = threadIdx.x;
+    const int x0 = blockIdx.x * 64, y0 = blockIdx.y * 32;
     const uint8_t* img = gray + (size_t)frame * fstride;
-    int col[5];
-#pragma unroll
-    for (int j = 0; j < 5; ++j) {
-        const uint8_t* row = img + (size_t)psl_reflect101i(y + j - 2, P.h) * stride;
-        int s = 0;
-#pragma unroll
-        for (int k = 0; k < 5; ++k) s += P.lbdK[k] * row[psl_reflect101i(x + k - 2, P.w)];
-        col[j] = s;
+    // s_in[r][c] = pixel (x0 - 4 + c, y0 - 3 + r), c in [0, 72): columns x0-3 .. x0+66 are needed (c = 1 .. 70)
+    const bool fast = x0 >= 4 && x0 + 68 <= P.w && ((reinterpret_cast<uintptr_t>(img) | (uintptr_t)stride) & 3) == 0;
+    if (fast) {
+        for (int k = tid; k < 38 * 18; k += 256) {
+            const int r = k / 18, c4 = k - r * 18;
+            const int gy = psl_reflect101i(y0 + r - 3, P.h);
+            reinterpret_cast<uint32_t*>(s_in)[r * 18 + c4] = *reinterpret_cast<const uint32_t*>(img + (size_t)gy * stride + x0 - 4 + c4 * 4);
+        }
+    } else {
+        for (int k = tid; k < 38 * 72; k += 256) {
+            const int r = k / 72, c = k - r * 72;
+            s_in[r * 72 + c] = img[(size_t)psl_reflect101i(y0 + r - 3, P.h) * stride + psl_reflect101i(x0 - 4 + c, P.w)];
+        }
     }
-    int s = 0;
-#pragma unroll
-    for (int j = 0; j < 5; ++j) s += P.lbdK[j] * col[j];
-    int v = (s + (1 << 15)) >> 16;
-    blur[(size_t)frame * P.w * P.h + (size_t)y * P.w + x] = (uint8_t)(v > 255 ? 255 : v);
-}
-
-__global__ __launch_bounds__(256) void k_lbd_sobel(LineParams P, const uint8_t* __restrict__ blur, short* __restrict__ dxo, short* __restrict__ dyo) {
-    const int frame = blockIdx.z;
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= P.w || y >= P.h) return;
-    const uint8_t* b = blur + (size_t)frame * P.w * P.h;
-    const int xm = psl_reflect101i(x - 1, P.w), xp = psl_reflect101i(x + 1, P.w);
-    const int ym = psl_reflect101i(y - 1, P.h), yp = psl_reflect101i(y + 1, P.h);
-    const int a00 = b[(size_t)ym * P.w + xm], a01 = b[(size_t)ym * P.w + x], a02 = b[(size_t)ym * P.w + xp];
-    const int a10 = b[(size_t)y * P.w + xm], a12 = b[(size_t)y * P.w + xp];
-    const int a20 = b[(size_t)yp * P.w + xm], a21 = b[(size_t)yp * P.w + x], a22 = b[(size_t)yp * P.w + xp];
-    const size_t o = (size_t)frame * P.w * P.h + (size_t)y * P.w + x;
-    dxo[o] = (short)((a02 + 2 * a12 + a22) - (a00 + 2 * a10 + a20));
-    dyo[o] = (short)((a20 + 2 * a21 + a22) - (a00 + 2 * a01 + a02));
+    __syncthreads();
+    const int K0 = P.lbdK[0], K1 = P.lbdK[1], K2 = P.lbdK[2];
+    for (int k = tid; k < 38 * 66; k += 256) {  // row pass at blurred columns x0-1 .. x0+64 (index j = 0..65)
+        const int r = k / 66, j = k - r * 66;
+        const uint8_t* in = &s_in[r * 72 + j + 1];  // blurred column x0-1+j reads input x0-3+j .. x0+1+j = c (j+1)..(j+5)
+        s_row[r * 68 + j] = (uint16_t)(K0 * (in[0] + in[4]) + K1 * (in[1] + in[3]) + K2 * in[2]);
+    }
+    __syncthreads();
+    for (int k = tid; k < 34 * 66; k += 256) {  // column pass at blurred rows y0-1 .. y0+32 (index r = 0..33)
+        const int r = k / 66, j = k - r * 66;
+        const uint16_t* rs = &s_row[r * 68 + j];  // blurred row y0-1+r reads input rows y0-3+r .. = s_row rows r .. r+4
+        const int sum = K0 * ((int)rs[0] + (int)rs[4 * 68]) + K1 * ((int)rs[68] + (int)rs[3 * 68]) + K2 * (int)rs[2 * 68];
+        const int v = (sum + (1 << 15)) >> 16;
+        s_bl[r * 68 + j] = (uint8_t)(v > 255 ? 255 : v);
+    }
+    __syncthreads();
+    for (int k = tid; k < 32 * 64; k += 256) {  // Sobel 3x3
+        const int oy = k >> 6, ox = k & 63;
+        const int x = x0 + ox, y = y0 + oy;
+        if (x >= P.w || y >= P.h) continue;
+        const uint8_t* b = &s_bl[(oy + 1) * 68 + ox + 1];
+        const int a00 = b[-68 - 1], a01 = b[-68], a02 = b[-68 + 1], a10 = b[-1], a12 = b[1], a20 = b[68 - 1], a21 = b[68], a22 = b[68 + 1];
+        dxy[(size_t)frame * P.w * P.h + (size_t)y * P.w + x] =
+            make_short2((short)((a02 + 2 * a12 + a22) - (a00 + 2 * a10 + a20)), (short)((a20 + 2 * a21 + a22) - (a00 + 2 * a01 + a02)));
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -398,7 +413,7 @@ __constant__ int c_lbd_combos[32][2] = {{0, 1}, {0, 2}, {0, 3}, {0, 4}, {0, 5}, 
                                         {2, 3}, {2, 4}, {2, 5}, {2, 6}, {2, 7}, {2, 8}, {3, 4}, {3, 5}, {3, 6}, {3, 7}, {3, 8},
                                         {4, 5}, {4, 6}, {4, 7}, {4, 8}, {5, 6}, {5, 7}, {5, 8}, {6, 7}, {6, 8}, {7, 8}};
 
-__global__ __launch_bounds__(256) void k_lbd(LineParams P, const short* __restrict__ dxI, const short* __restrict__ dyI,
+__global__ __launch_bounds__(256) void k_lbd(LineParams P, const short2* __restrict__ dxyI,
                                               const PslKeyLine* __restrict__ kls, const int* __restrict__ nkl, uint8_t* __restrict__ desc,
                                               float* __restrict__ fdesc) {
     __shared__ float s_row[4][63][8];
@@ -407,8 +422,7 @@ __global__ __launch_bounds__(256) void k_lbd(LineParams P, const short* __restri
     const int line = blockIdx.x * 4 + wave;
     const bool active = line < nkl[frame];
     const PslKeyLine kl = kls[(size_t)frame * P.maxkl + (active ? line : 0)];
-    const short* pdx = dxI + (size_t)frame * P.w * P.h;
-    const short* pdy = dyI + (size_t)frame * P.w * P.h;
+    const short2* pdxy = dxyI + (size_t)frame * P.w * P.h;
     const int NB = 9, WB = 7;
     const short realWidth = (short)P.w, imageWidth = (short)(realWidth - 1), imageHeight = (short)(P.h - 1);
     const short lengthOfLSP = (short)kl.numOfPixels;
@@ -429,7 +443,8 @@ __global__ __launch_bounds__(256) void k_lbd(LineParams P, const short* __restri
             const short xCor = (t < 0) ? 0 : (t > imageWidth) ? imageWidth : t;
             t = (short)__builtin_roundf(sCorY);
             const short yCor = (t < 0) ? 0 : (t > imageHeight) ? imageHeight : t;
-            const float gx = (float)pdx[(int)yCor * realWidth + xCor], gy = (float)pdy[(int)yCor * realWidth + xCor];
+            const short2 g2 = pdxy[(int)yCor * realWidth + xCor];
+            const float gx = (float)g2.x, gy = (float)g2.y;
             const float gDL = PSL_FADD(PSL_FMUL(gx, dL0), PSL_FMUL(gy, dL1));
             const float gDO = PSL_FADD(PSL_FMUL(gx, dO0), PSL_FMUL(gy, dO1));
             if (gDL > 0) pL = PSL_FADD(pL, gDL); else nL = PSL_FSUB(nL, gDL);

@@ -15,7 +15,7 @@
 
 #define PSL_EDGE 16          // minBorderX = EDGE_THRESHOLD - 3 (src/ORBextractor.cc:773)
 #define PSL_MAXCELL 64       // largest FAST cell interior handled by k_fast_cells
-#define PSL_FAST_TP 72       // LDS pitch of the (cell+6)^2 image tile
+#define PSL_FAST_TP 76       // LDS pitch of the (cell+6)^2 image tile (+3 alignment slack, multiple of 4)
 #define PSL_FAST_SP 68       // LDS pitch of the (cell+2)^2 score map
 
 struct OrbLevelP {
@@ -133,7 +133,7 @@ __device__ __forceinline__ int psl_fast_score(const uint8_t* c, const int tp) {
 
 __global__ __launch_bounds__(256, 8) void k_fast_cells(OrbParams P, FrameSrc S, int* __restrict__ cellcnt,
                                                      uint32_t* __restrict__ cellcand) {
-    __shared__ uint8_t s_tile[(PSL_MAXCELL + 6) * PSL_FAST_TP];
+    __shared__ __attribute__((aligned(16))) uint8_t s_tile[(PSL_MAXCELL + 6) * PSL_FAST_TP + 8];
     __shared__ uint8_t s_score[(PSL_MAXCELL + 2) * PSL_FAST_SP];
     __shared__ int s_cnt[2][64];  // survivors per (pass, wave) at iniTh / minTh
     __shared__ int s_off[2][65];
@@ -164,9 +164,22 @@ __global__ __launch_bounds__(256, 8) void k_fast_cells(OrbParams P, FrameSrc S, 
 
     int pitch;
     const uint8_t* img = psl_level_ptr(P, S, level, frame, &pitch);
-    for (int y = wave; y < th; y += 4) {
-        const uint8_t* row = img + (size_t)(iniY + y) * pitch + iniX;
-        for (int x = lane; x < tw; x += 64) s_tile[y * PSL_FAST_TP + x] = row[x];
+    // tile rows as aligned dwords when the level's rows are 4-byte aligned (always for levels >= 1): the
+    // tile then starts `toff` bytes into its first dword
+    const bool aligned4 = ((reinterpret_cast<uintptr_t>(img) | (uintptr_t)pitch) & 3) == 0;
+    const int toff = aligned4 ? (iniX & 3) : 0;
+    if (aligned4) {
+        const int ndw = (toff + tw + 3) >> 2;  // <= 19
+        for (int k = tid; k < th * ndw; k += 256) {
+            const int y = k / ndw, d = k - y * ndw;
+            reinterpret_cast<uint32_t*>(s_tile)[y * (PSL_FAST_TP / 4) + d] =
+                *reinterpret_cast<const uint32_t*>(img + (size_t)(iniY + y) * pitch + (iniX - toff) + d * 4);
+        }
+    } else {
+        for (int y = wave; y < th; y += 4) {
+            const uint8_t* row = img + (size_t)(iniY + y) * pitch + iniX;
+            for (int x = lane; x < tw; x += 64) s_tile[y * PSL_FAST_TP + x] = row[x];
+        }
     }
     for (int k = tid; k < (ih + 2) * PSL_FAST_SP; k += 256) s_score[k] = 0;
     if (tid < 128) (&s_cnt[0][0])[tid] = 0;
@@ -185,7 +198,7 @@ __global__ __launch_bounds__(256, 8) void k_fast_cells(OrbParams P, FrameSrc S, 
         bool pass = false;
         if (idx < npix) {
             const int y = idx / iw, x = idx - y * iw;
-            const uint8_t* c = &s_tile[(y + 3) * PSL_FAST_TP + x + 3];
+            const uint8_t* c = &s_tile[(y + 3) * PSL_FAST_TP + x + 3 + toff];
             const int hi = c[0] + minTh, lo = c[0] - minTh;
             const int r0 = c[3 * PSL_FAST_TP], r8 = c[-3 * PSL_FAST_TP], r4 = c[3], r12 = c[-3];
             const int r2 = c[2 * PSL_FAST_TP + 2], r10 = c[-2 * PSL_FAST_TP - 2], r6 = c[-2 * PSL_FAST_TP + 2], r14 = c[2 * PSL_FAST_TP - 2];
@@ -204,7 +217,7 @@ __global__ __launch_bounds__(256, 8) void k_fast_cells(OrbParams P, FrameSrc S, 
     for (int i = tid; i < nlist; i += 256) {
         const int idx = s_list[i];
         const int y = idx / iw, x = idx - y * iw;
-        int s = psl_fast_score(&s_tile[(y + 3) * PSL_FAST_TP + x + 3], PSL_FAST_TP);
+        int s = psl_fast_score(&s_tile[(y + 3) * PSL_FAST_TP + x + 3 + toff], PSL_FAST_TP);
         s = s < minTh ? 0 : (s > 255 ? 255 : s);
         s_score[(y + 1) * PSL_FAST_SP + x + 1] = (uint8_t)s;
     }
@@ -543,10 +556,13 @@ __global__ __launch_bounds__(256) void k_blur7(OrbParams P, FrameSrc S, uint8_t*
     const int K0 = P.blurK[0], K1 = P.blurK[1], K2 = P.blurK[2], K3 = P.blurK[3];
     for (int k = tid; k < rows * 16; k += 256) {  // row pass: 4 outputs from 10 input bytes
         const int r = k >> 4, g = k & 15;
-        const uint8_t* in = &s_in[r * 72 + g * 4 + 1];  // output x = x0 + 4g + j reads bytes (4g + j + 1) .. +6
+        // output x = x0 + 4g + j reads bytes (4g + j + 1) .. (4g + j + 7) of the row: three aligned dwords
+        const uint32_t* in32 = reinterpret_cast<const uint32_t*>(&s_in[r * 72 + g * 4]);
+        const uint32_t w0 = in32[0], w1 = in32[1], w2 = in32[2];
         int v[10];
-#pragma unroll
-        for (int j = 0; j < 10; ++j) v[j] = in[j];
+        v[0] = (w0 >> 8) & 0xff; v[1] = (w0 >> 16) & 0xff; v[2] = w0 >> 24;
+        v[3] = w1 & 0xff; v[4] = (w1 >> 8) & 0xff; v[5] = (w1 >> 16) & 0xff; v[6] = w1 >> 24;
+        v[7] = w2 & 0xff; v[8] = (w2 >> 8) & 0xff; v[9] = (w2 >> 16) & 0xff;
         uint16_t o[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j)

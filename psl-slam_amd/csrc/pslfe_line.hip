@@ -40,9 +40,7 @@ struct pslfe_line {
     double* d_lineEq = nullptr;
     int* d_nkl = nullptr;
     int* d_status = nullptr;
-    uint8_t* d_lbdblur = nullptr;
-    short* d_dx = nullptr;
-    short* d_dy = nullptr;
+    short2* d_dxy = nullptr;
     float* d_rawfans = nullptr;
     float* d_fans = nullptr;
     int* d_nfans = nullptr;
@@ -52,10 +50,10 @@ struct pslfe_line {
         hipFree(M.lines0); hipFree(M.lines1); hipFree(M.merged); hipFree(M.angles); hipFree(M.length); hipFree(M.order); hipFree(M.pos);
         hipFree(M.adj); hipFree(M.code); hipFree(M.clist); hipFree(M.coff); hipFree(M.work); hipFree(M.bits); hipFree(M.stage);
         M = MergeScratch{};
-        hipFree(d_kls); hipFree(d_ldesc); hipFree(d_fdesc); hipFree(d_lineEq); hipFree(d_nkl); hipFree(d_status); hipFree(d_lbdblur);
-        hipFree(d_dx); hipFree(d_dy); hipFree(d_rawfans); hipFree(d_fans); hipFree(d_nfans); hipFree(d_tmplines);
-        d_kls = nullptr; d_ldesc = nullptr; d_fdesc = nullptr; d_lineEq = nullptr; d_nkl = nullptr; d_status = nullptr; d_lbdblur = nullptr;
-        d_dx = nullptr; d_dy = nullptr; d_rawfans = nullptr; d_fans = nullptr; d_nfans = nullptr; d_tmplines = nullptr;
+        hipFree(d_kls); hipFree(d_ldesc); hipFree(d_fdesc); hipFree(d_lineEq); hipFree(d_nkl); hipFree(d_status); hipFree(d_dxy);
+        hipFree(d_rawfans); hipFree(d_fans); hipFree(d_nfans); hipFree(d_tmplines);
+        d_kls = nullptr; d_ldesc = nullptr; d_fdesc = nullptr; d_lineEq = nullptr; d_nkl = nullptr; d_status = nullptr; d_dxy = nullptr;
+        d_rawfans = nullptr; d_fans = nullptr; d_nfans = nullptr; d_tmplines = nullptr;
         hipFree(d_trig); d_trig = nullptr;
         hipFree(d_usedbits); d_usedbits = nullptr;
         hipFree(d_in); hipFree(d_scaled); hipFree(d_angdeg); hipFree(d_modgrad); hipFree(d_used); hipFree(d_reg);
@@ -141,9 +139,7 @@ struct pslfe_line {
         PSL_HIP(hipMalloc((void**)&d_lineEq, F * Q.maxkl * 3 * sizeof(double)));
         PSL_HIP(hipMalloc((void**)&d_nkl, F * sizeof(int)));
         PSL_HIP(hipMalloc((void**)&d_status, F * sizeof(int)));
-        PSL_HIP(hipMalloc((void**)&d_lbdblur, F * (size_t)w * h));
-        PSL_HIP(hipMalloc((void**)&d_dx, F * (size_t)w * h * sizeof(short)));
-        PSL_HIP(hipMalloc((void**)&d_dy, F * (size_t)w * h * sizeof(short)));
+        PSL_HIP(hipMalloc((void**)&d_dxy, F * (size_t)w * h * sizeof(short2)));
         PSL_HIP(hipMalloc((void**)&d_rawfans, F * PSL_FAN_CAP * 4 * sizeof(float)));
         PSL_HIP(hipMalloc((void**)&d_fans, F * PSL_FAN_CAP * 4 * sizeof(float)));
         PSL_HIP(hipMalloc((void**)&d_nfans, F * sizeof(int)));
@@ -207,17 +203,15 @@ struct pslfe_line {
     int run_lbd(const uint8_t* d_gray, int nframes, int stride, size_t frame_stride, bool want_float) {
         PSL_HIP(hipSetDevice(ctx->device));
         hipStream_t st = ctx->stream;
-        dim3 grid((P.w + 63) / 64, (P.h + 3) / 4, nframes);
         {
             PSL_STAGE_BEGIN(ctx, "line.lbd_pre");
-            k_lbd_blur5<<<grid, 256, 0, st>>>(P, d_gray, stride, frame_stride, d_lbdblur);
-            k_lbd_sobel<<<grid, 256, 0, st>>>(P, d_lbdblur, d_dx, d_dy);
+            k_lbd_pre<<<dim3((P.w + 63) / 64, (P.h + 31) / 32, nframes), 256, 0, st>>>(P, d_gray, stride, frame_stride, d_dxy);
             PSL_STAGE_END(ctx, "line.lbd_pre");
         }
         {
             PSL_STAGE_BEGIN(ctx, "line.lbd");
             const int per_frame = std::min(P.maxkl, std::max(P.nfeatures, 1));
-            k_lbd<<<dim3((per_frame + 3) / 4, nframes), 256, 0, st>>>(P, d_dx, d_dy, d_kls, d_nkl, d_ldesc, want_float ? d_fdesc : nullptr);
+            k_lbd<<<dim3((per_frame + 3) / 4, nframes), 256, 0, st>>>(P, d_dxy, d_kls, d_nkl, d_ldesc, want_float ? d_fdesc : nullptr);
             PSL_STAGE_END(ctx, "line.lbd");
         }
         PSL_HIP(hipGetLastError());
@@ -437,8 +431,9 @@ int pslfe_line_debug_sobel(pslfe_line* line, int frame, int16_t* dx, int16_t* dy
     PSL_HIP(hipSetDevice(line->ctx->device));
     PSL_HIP(hipStreamSynchronize(line->ctx->stream));
     const size_t npx = (size_t)line->P.w * line->P.h;
-    PSL_HIP(hipMemcpy(dx, line->d_dx + frame * npx, npx * sizeof(short), hipMemcpyDeviceToHost));
-    PSL_HIP(hipMemcpy(dy, line->d_dy + frame * npx, npx * sizeof(short), hipMemcpyDeviceToHost));
+    std::vector<short2> tmp(npx);
+    PSL_HIP(hipMemcpy(tmp.data(), line->d_dxy + frame * npx, npx * sizeof(short2), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < npx; ++i) { dx[i] = tmp[i].x; dy[i] = tmp[i].y; }
     return PSLFE_OK;
 }
 

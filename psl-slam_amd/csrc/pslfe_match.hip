@@ -261,12 +261,12 @@ __global__ __launch_bounds__(256) void k_window_eval(MatchArgs A) {
 // query" using the cached top-4 lists (thread per query); a query whose whole list is blocked while it has
 // more candidates is re-scanned in full by a wave (rare).  Then the rotation histogram and the outputs.
 // MODE 0: SearchByProjection(cur,last) (:1328-1470); MODE 1: SearchByProjection(F, MapPoints) (:45-129).
-template <int MODE>
-__global__ __launch_bounds__(1024) void k_window_resolve(MatchArgs A) {
-    __shared__ int s_choice[PSL_QMAX];
-    __shared__ int s_blocker[PSL_QMAX];
-    __shared__ uint8_t s_bin[PSL_QMAX];
-    __shared__ uint8_t s_slow[PSL_QMAX];
+template <int MODE, int QM, int BS>
+__global__ __launch_bounds__(BS) void k_window_resolve(MatchArgs A) {
+    __shared__ int s_choice[QM];
+    __shared__ int s_blocker[QM];
+    __shared__ uint8_t s_bin[QM];
+    __shared__ uint8_t s_slow[QM];
     __shared__ int s_hist[PSL_HISTO];
     __shared__ int s_ind[3];
     __shared__ int s_flag[3];  // 0: changed, 1: nmatches, 2: any slow
@@ -274,17 +274,17 @@ __global__ __launch_bounds__(1024) void k_window_resolve(MatchArgs A) {
     const int pair = blockIdx.x, slot = A.slot0 + pair, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const FrameStore& S = A.S;
     const FrameView V = psl_frame_view(S, slot);
-    const int n = V.n;
+    const int n = V.n < QM ? V.n : QM;
     int nq = A.nq_arr ? A.nq_arr[pair] : A.nq_single;
-    nq = min(min(nq, A.qstride), PSL_QMAX);
+    nq = min(min(nq, A.qstride), QM);
     const PslProjQuery* Q = A.q + (size_t)pair * A.qstride;
     const uint32_t* QD = reinterpret_cast<const uint32_t*>(A.qdesc + (size_t)pair * A.qstride * 32);
     const uint8_t* taken = A.taken ? A.taken + (size_t)pair * S.cap : nullptr;
     const uint32_t* TK = A.topk + (size_t)pair * A.qstride * 4;
     const uint8_t* MORE = A.more + (size_t)pair * A.qstride;
 
-    for (int i = tid; i < nq; i += 1024) s_choice[i] = -2;
-    for (int i = tid; i < n; i += 1024) s_blocker[i] = 0x7fffffff;
+    for (int i = tid; i < nq; i += BS) s_choice[i] = -2;
+    for (int i = tid; i < n; i += BS) s_blocker[i] = 0x7fffffff;
     __syncthreads();
 
     // decide a query from its two best non-blocked keys
@@ -303,7 +303,7 @@ __global__ __launch_bounds__(1024) void k_window_resolve(MatchArgs A) {
     for (int iter = 0; iter <= nq; ++iter) {
         if (tid == 0) { s_flag[0] = 0; s_flag[2] = 0; }
         __syncthreads();
-        for (int qi = tid; qi < nq; qi += 1024) {  // fast path: cached lists
+        for (int qi = tid; qi < nq; qi += BS) {  // fast path: cached lists
             uint32_t k1 = PSL_KEY_INF, k2 = PSL_KEY_INF;
             int found = 0;
             bool exhausted = true;  // true if the list ended before we had what we need
@@ -325,7 +325,7 @@ __global__ __launch_bounds__(1024) void k_window_resolve(MatchArgs A) {
         }
         __syncthreads();
         if (s_flag[2]) {  // slow path: full window scan with the current blockers, one wave per query
-            for (int qi = wave; qi < nq; qi += 16) {
+            for (int qi = wave; qi < nq; qi += BS / 64) {
                 if (!s_slow[qi]) continue;
                 const PslProjQuery q = Q[qi];
                 uint32_t qd[8];
@@ -342,9 +342,9 @@ __global__ __launch_bounds__(1024) void k_window_resolve(MatchArgs A) {
         const int changed = s_flag[0];
         __syncthreads();
         if (!changed) break;
-        for (int i = tid; i < n; i += 1024) s_blocker[i] = 0x7fffffff;
+        for (int i = tid; i < n; i += BS) s_blocker[i] = 0x7fffffff;
         __syncthreads();
-        for (int qi = tid; qi < nq; qi += 1024) {
+        for (int qi = tid; qi < nq; qi += BS) {
             const int c = s_choice[qi];
             if (c >= 0 && Q[qi].blocks) atomicMin(&s_blocker[c], qi);
         }
@@ -358,7 +358,7 @@ __global__ __launch_bounds__(1024) void k_window_resolve(MatchArgs A) {
     const bool ori = MODE == 0 && A.check_ori;
     if (ori) {
         const float factor = 1.0f / PSL_HISTO;
-        for (int qi = tid; qi < nq; qi += 1024) {
+        for (int qi = tid; qi < nq; qi += BS) {
             const int c = s_choice[qi];
             if (c < 0) continue;
             float rot = PSL_FSUB(Q[qi].angle, V.kps[c].angle);
@@ -385,11 +385,11 @@ __global__ __launch_bounds__(1024) void k_window_resolve(MatchArgs A) {
         __syncthreads();
     }
     // owners: the last query that assigned a keypoint, unless one of its assignments was filtered
-    for (int i = tid; i < n; i += 1024) s_blocker[i] = -1;
+    for (int i = tid; i < n; i += BS) s_blocker[i] = -1;
     __syncthreads();
     int local = 0;
     int* match = A.match + (size_t)pair * A.qstride;
-    for (int qi = tid; qi < nq; qi += 1024) {
+    for (int qi = tid; qi < nq; qi += BS) {
         const int c = s_choice[qi];
         bool good = c >= 0;
         if (good) atomicMax(&s_blocker[c], qi);
@@ -399,7 +399,7 @@ __global__ __launch_bounds__(1024) void k_window_resolve(MatchArgs A) {
     }
     __syncthreads();
     if (ori)
-        for (int qi = tid; qi < nq; qi += 1024) {
+        for (int qi = tid; qi < nq; qi += BS) {
             const int c = s_choice[qi];
             if (c < 0) continue;
             const int b = s_bin[qi];
@@ -411,7 +411,7 @@ __global__ __launch_bounds__(1024) void k_window_resolve(MatchArgs A) {
     __syncthreads();
     if (A.assigned) {
         int* asg = A.assigned + (size_t)pair * S.cap;
-        for (int i = tid; i < V.M.n; i += 1024) asg[i] = i < n ? s_blocker[i] : -1;
+        for (int i = tid; i < V.M.n; i += BS) asg[i] = i < n ? s_blocker[i] : -1;
     }
     if (tid == 0) A.nmatches[pair] = s_flag[1];
 }
@@ -489,7 +489,9 @@ int host_search(pslfe_frame* f, int slot, const PslProjQuery* queries, const uin
     {
         PSL_STAGE_BEGIN(f->ctx, "match.window");
         k_window_eval<<<dim3((nq + 3) / 4, 1), 256, 0, st>>>(A);
-        if (mode == 0) k_window_resolve<0><<<1, 1024, 0, st>>>(A); else k_window_resolve<1><<<1, 1024, 0, st>>>(A);
+        const bool small = nq <= 2048 && f->cap <= 2048;
+        if (mode == 0) { if (small) k_window_resolve<0, 2048, 256><<<1, 256, 0, st>>>(A); else k_window_resolve<0, PSL_QMAX, 1024><<<1, 1024, 0, st>>>(A); }
+        else { if (small) k_window_resolve<1, 2048, 256><<<1, 256, 0, st>>>(A); else k_window_resolve<1, PSL_QMAX, 1024><<<1, 1024, 0, st>>>(A); }
         PSL_STAGE_END(f->ctx, "match.window");
     }
     PSL_HIP(hipGetLastError());
@@ -647,7 +649,10 @@ int pslfe_orb_search_by_projection_last_device(pslfe_frame* cur, int slot0, int 
     {
         PSL_STAGE_BEGIN(cur->ctx, "match.window");
         k_window_eval<<<dim3((std::min(qstride, PSL_QMAX) + 3) / 4, npairs), 256, 0, cur->ctx->stream>>>(A);
-        k_window_resolve<0><<<npairs, 1024, 0, cur->ctx->stream>>>(A);
+        // few frames: one big workgroup per frame finishes its frame sooner; many frames: small workgroups so
+        // that 8 frames share a CU and overlap their barrier-separated phases
+        if (qstride <= 2048 && cur->cap <= 2048 && npairs >= 4 * cur->ctx->cu_count) k_window_resolve<0, 2048, 256><<<npairs, 256, 0, cur->ctx->stream>>>(A);
+        else k_window_resolve<0, PSL_QMAX, 1024><<<npairs, 1024, 0, cur->ctx->stream>>>(A);
         PSL_STAGE_END(cur->ctx, "match.window");
     }
     PSL_HIP(hipGetLastError());
