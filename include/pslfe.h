@@ -86,6 +86,17 @@ int pslfe_device_free(pslfe_ctx* ctx, void* d_ptr);
 int pslfe_device_upload(pslfe_ctx* ctx, void* d_dst, const void* src, size_t bytes);
 int pslfe_device_download(pslfe_ctx* ctx, void* dst, const void* d_src, size_t bytes);
 
+/* ---- input conversions (Tracking::GrabImageRGBD src/Tracking.cc:214-240) --------------------- */
+/* == cvtColor(im, gray, CV_RGB2GRAY | CV_BGR2GRAY) src/Tracking.cc:219-232 on 8UC3 frames (the 4-channel
+ *    variants :226-231 drop alpha first and are the same arithmetic).  is_rgb: mbRGB.  Frame f at
+ *    d_rgb + f*frame_stride, rows `stride` bytes apart; d_gray packed [nframes][h][w]. Asynchronous. */
+int pslfe_rgb_to_gray_device(pslfe_ctx* ctx, const uint8_t* d_rgb, int nframes, int w, int h, int stride,
+                             size_t frame_stride, int is_rgb, uint8_t* d_gray);
+int pslfe_rgb_to_gray(pslfe_ctx* ctx, const uint8_t* rgb, int w, int h, int stride, int is_rgb, uint8_t* gray);
+/* == imDepth.convertTo(imDepth, CV_32F, mDepthMapFactor) src/Tracking.cc:234-235 on CV_16U depth. */
+int pslfe_depth_to_float_device(pslfe_ctx* ctx, const uint16_t* d_depth, size_t n, float factor, float* d_out);
+int pslfe_depth_to_float(pslfe_ctx* ctx, const uint16_t* depth, size_t n, float factor, float* out);
+
 /* ---- ORB extractor -------------------------------------------------------------------------- */
 /* == ORBextractor::ORBextractor(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST)
  *    src/ORBextractor.cc:410-470; object created once in Tracking (src/Tracking.cc:120).
@@ -245,6 +256,33 @@ int pslfe_frame_set(pslfe_frame* f, int slot, const PslKeyPoint* kps, const uint
                     int n, float min_x, float min_y, float max_x, float max_y);
 /* All frames of the last batch of `orb` -> slots 0..nframes-1, HBM to HBM, asynchronous. */
 int pslfe_frame_set_from_orb(pslfe_frame* f, pslfe_orb* orb, float min_x, float min_y, float max_x, float max_y);
+/* Pinhole + radial-tangential camera of the settings YAML (Examples/RGB-D/TUM1.yaml; src/Tracking.cc:62-94):
+ * mK entries, mDistCoef (k1 k2 p1 p2 k3) and mbf, all as the reference stores them (float). */
+typedef struct PslCamera {
+    float fx, fy, cx, cy;
+    float k1, k2, p1, p2, k3;
+    float bf;
+} PslCamera;
+
+/* == Frame::ComputeImageBounds src/Frame.cc:1135-1168: bounds = {mnMinX, mnMinY, mnMaxX, mnMaxY}
+ *    (the argument order of pslfe_frame_set). */
+int pslfe_image_bounds(pslfe_frame* f, const PslCamera* cam, int cols, int rows, float* bounds);
+
+/* == The RGB-D part of the Frame constructor (src/Frame.cc:105-171) for one frame: UndistortKeyPoints
+ *    :1062-1092 (cv::undistortPoints with P = K, skipped when k1 == 0 exactly as the reference does),
+ *    ComputeStereoFromRGBD :1342-1363 (depth sampled at the DISTORTED keypoint, truncated to integer
+ *    pixel; mvuRight = xUn - mbf/d, both -1 where d <= 0), ComputeImageBounds (first-frame statics) and
+ *    AssignFeaturesToGrid on the undistorted points.  depth: CV_32F image (metres), host memory,
+ *    depth_stride in floats.  The slot then holds mvKeysUn / mvuRight / mvDepth (pslfe_frame_fetch). */
+int pslfe_frame_set_rgbd(pslfe_frame* f, int slot, const PslKeyPoint* kps, const uint8_t* desc, int n, const float* depth,
+                         int width, int height, int depth_stride, const PslCamera* cam);
+/* Same for every frame of the last batch of `orb` (slots 0..nframes-1), HBM to HBM, asynchronous.
+ * d_depth: [nframes][height][width] float in HBM. */
+int pslfe_frame_set_from_orb_rgbd(pslfe_frame* f, pslfe_orb* orb, const float* d_depth, int width, int height,
+                                  const PslCamera* cam);
+/* mvKeysUn, mvDepth, mvuRight of a slot (any pointer may be NULL). */
+int pslfe_frame_fetch(pslfe_frame* f, int slot, PslKeyPoint* kps_un, float* depth, float* uright, int cap, int* n);
+
 /* Tap for parity tests: CSR of mGrid in the order GetFeaturesInArea visits it (cell = ix*48+iy):
  * start[64*48+1], idx[n]. */
 int pslfe_frame_debug_grid(pslfe_frame* f, int slot, int32_t* start, int32_t* idx, int cap, int* n);

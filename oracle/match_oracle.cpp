@@ -237,3 +237,72 @@ int pso_line_match_nnr(const uint8_t* d1, int n1, const uint8_t* d2, int n2, flo
 }
 
 }  // extern "C"
+
+// ---- Frame post-processing between extraction and matching ----------------
+//   cvtColor RGB/BGR -> GRAY (src/Tracking.cc:219-232): OpenCV 8-bit fixed point, (R*4899 + G*9617 + B*1868 + 8192) >> 14
+//   depth.convertTo(CV_32F, factor) (src/Tracking.cc:234-235): (float)d * (float)factor
+//   Frame::UndistortKeyPoints (src/Frame.cc:1062-1092) -> cv::undistortPoints(mat, mat, K, dist, Mat(), K): 5 fixed
+//        iterations in double, restated from the OpenCV 3.2 algorithm (Appendix A; not in the reference tree)
+//   Frame::ComputeImageBounds (src/Frame.cc:1135-1168), Frame::ComputeStereoFromRGBD (src/Frame.cc:1342-1363)
+namespace {
+void undistort_point(double u, double v, const double* K /*fx,fy,cx,cy*/, const double* k /*k1,k2,p1,p2,k3*/, float* ox, float* oy) {
+    const double fx = K[0], fy = K[1], cx = K[2], cy = K[3], ifx = 1. / fx, ify = 1. / fy;
+    double x = (u - cx) * ifx, y = (v - cy) * ify;
+    const double x0 = x, y0 = y;
+    for (int j = 0; j < 5; ++j) {
+        const double r2 = x * x + y * y;
+        const double icdist = (1 + ((0 * r2 + 0) * r2 + 0) * r2) / (1 + ((k[4] * r2 + k[1]) * r2 + k[0]) * r2);
+        const double deltaX = 2 * k[2] * x * y + k[3] * (r2 + 2 * x * x) + 0 * r2 + 0 * r2 * r2;
+        const double deltaY = k[2] * (r2 + 2 * y * y) + 2 * k[3] * x * y + 0 * r2 + 0 * r2 * r2;
+        x = (x0 - deltaX) * icdist;
+        y = (y0 - deltaY) * icdist;
+    }
+    const double xx = fx * x + 0 * y + cx, yy = 0 * x + fy * y + cy, ww = 1. / (0 * x + 0 * y + 1);
+    *ox = (float)(xx * ww);
+    *oy = (float)(yy * ww);
+}
+}  // namespace
+
+extern "C" {
+
+void pso_rgb_to_gray(const uint8_t* rgb, int w, int h, int stride, int is_rgb, uint8_t* gray) {
+    for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x) {
+            const uint8_t* p = rgb + (size_t)y * stride + 3 * x;
+            const int r = is_rgb ? p[0] : p[2], g = p[1], b = is_rgb ? p[2] : p[0];
+            gray[(size_t)y * w + x] = (uint8_t)((r * 4899 + g * 9617 + b * 1868 + (1 << 13)) >> 14);
+        }
+}
+
+void pso_depth_to_float(const uint16_t* d, int n, float factor, float* out) {
+    for (int i = 0; i < n; ++i) out[i] = (float)d[i] * factor;
+}
+
+// bounds: mnMinX, mnMinY, mnMaxX, mnMaxY
+void pso_image_bounds(int cols, int rows, const float* K, const float* dist, float* bounds) {
+    if (dist[0] != 0.0f) {
+        const double Kd[4] = {K[0], K[1], K[2], K[3]}, kd[5] = {dist[0], dist[1], dist[2], dist[3], dist[4]};
+        float cx[4], cy[4];
+        const float src[4][2] = {{0.f, 0.f}, {(float)cols, 0.f}, {0.f, (float)rows}, {(float)cols, (float)rows}};
+        for (int i = 0; i < 4; ++i) undistort_point(src[i][0], src[i][1], Kd, kd, &cx[i], &cy[i]);
+        bounds[0] = std::min(cx[0], cx[2]); bounds[2] = std::max(cx[1], cx[3]);
+        bounds[1] = std::min(cy[0], cy[1]); bounds[3] = std::max(cy[2], cy[3]);
+    } else { bounds[0] = 0.0f; bounds[2] = (float)cols; bounds[1] = 0.0f; bounds[3] = (float)rows; }
+}
+
+// mvKeysUn, mvDepth, mvuRight from mvKeys and the float depth image
+void pso_frame_post_rgbd(const PsoKeyPoint* kps, int n, const float* depth, int w, int h, int dstride /*floats*/, const float* K, const float* dist,
+                         float mbf, PsoKeyPoint* kpsUn, float* mvDepth, float* mvuRight) {
+    const double Kd[4] = {K[0], K[1], K[2], K[3]}, kd[5] = {dist[0], dist[1], dist[2], dist[3], dist[4]};
+    for (int i = 0; i < n; ++i) {
+        kpsUn[i] = kps[i];
+        if (dist[0] != 0.0f) undistort_point(kps[i].x, kps[i].y, Kd, kd, &kpsUn[i].x, &kpsUn[i].y);
+        mvDepth[i] = -1; mvuRight[i] = -1;
+        const int v = (int)kps[i].y, u = (int)kps[i].x;
+        const float d = depth[(size_t)v * dstride + u];
+        if (d > 0) { mvDepth[i] = d; mvuRight[i] = kpsUn[i].x - mbf / d; }
+    }
+    (void)w; (void)h;
+}
+
+}  // extern "C"

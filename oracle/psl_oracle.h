@@ -99,6 +99,12 @@ int pso_line_search_by_projection(const PsoKeyLine* k, const uint8_t* desc, cons
                                   float minY, float maxX, float maxY, const PsoLineQuery* q, const uint8_t* qdesc, int nq,
                                   const uint8_t* taken, int mode, float nnratio, int* match, int* assigned);
 
+void pso_rgb_to_gray(const uint8_t* rgb, int w, int h, int stride, int is_rgb, uint8_t* gray);
+void pso_depth_to_float(const uint16_t* d, int n, float factor, float* out);
+void pso_image_bounds(int cols, int rows, const float* K, const float* dist, float* bounds);
+void pso_frame_post_rgbd(const PsoKeyPoint* kps, int n, const float* depth, int w, int h, int dstride, const float* K, const float* dist,
+                         float mbf, PsoKeyPoint* kpsUn, float* mvDepth, float* mvuRight);
+
 #ifdef __cplusplus
 }
 #endif

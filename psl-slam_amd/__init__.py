@@ -26,6 +26,7 @@ KEYLINE_DTYPE = np.dtype([("angle", "<f4"), ("class_id", "<i4"), ("octave", "<i4
                           ("lineLength", "<f4"), ("numOfPixels", "<i4")])
 PROJQUERY_DTYPE = np.dtype([("u", "<f4"), ("v", "<f4"), ("radius", "<f4"), ("ur", "<f4"), ("min_level", "<i4"),
                             ("max_level", "<i4"), ("angle", "<f4"), ("blocks", "<i4")])
+CAMERA_DTYPE = np.dtype([(k, "<f4") for k in ("fx", "fy", "cx", "cy", "k1", "k2", "p1", "p2", "k3", "bf")])
 assert KEYPOINT_DTYPE.itemsize == 28 and KEYLINE_DTYPE.itemsize == 68 and PROJQUERY_DTYPE.itemsize == 32
 
 
@@ -258,6 +259,27 @@ class ORBextractor:
             pass
 
 
+def rgb_to_gray(rgb, is_rgb=True, ctx=None):
+    """cvtColor(im, gray, CV_RGB2GRAY if mbRGB else CV_BGR2GRAY), src/Tracking.cc:219-232. rgb: (h, w, 3) u8."""
+    ctx = ctx or default_context()
+    rgb = np.ascontiguousarray(rgb, np.uint8)
+    h, w = rgb.shape[:2]
+    gray = np.zeros((h, w), np.uint8)
+    _check(lib().pslfe_rgb_to_gray(ctx._h, _ptr(rgb), C.c_int(w), C.c_int(h), C.c_int(3 * w), C.c_int(1 if is_rgb else 0),
+                                   _ptr(gray)), "pslfe_rgb_to_gray")
+    return gray
+
+
+def depth_to_float(depth, factor, ctx=None):
+    """imDepth.convertTo(imDepth, CV_32F, mDepthMapFactor), src/Tracking.cc:234-235. depth: u16 array."""
+    ctx = ctx or default_context()
+    depth = np.ascontiguousarray(depth, np.uint16)
+    out = np.zeros(depth.shape, np.float32)
+    _check(lib().pslfe_depth_to_float(ctx._h, _ptr(depth), C.c_size_t(depth.size), C.c_float(factor), _ptr(out)),
+           "pslfe_depth_to_float")
+    return out
+
+
 class FrameGrid:
     """Keypoints of up to `max_frames` frames on the 64x48 grid of include/Frame.h:45-46
     (== the part of ORB_SLAM2::Frame the matchers read: mvKeysUn, mDescriptors, mvuRight, mGrid)."""
@@ -280,6 +302,42 @@ class FrameGrid:
 
     def set_from_orb(self, orb, bounds):
         _check(lib().pslfe_frame_set_from_orb(self._h, orb._h, *[C.c_float(b) for b in bounds]), "pslfe_frame_set_from_orb")
+
+    def image_bounds(self, cam, cols, rows):
+        """Frame::ComputeImageBounds src/Frame.cc:1135-1168 -> (mnMinX, mnMinY, mnMaxX, mnMaxY)."""
+        b = np.zeros(4, np.float32)
+        cam = np.ascontiguousarray(cam, CAMERA_DTYPE).reshape(1)
+        _check(lib().pslfe_image_bounds(self._h, _ptr(cam), C.c_int(cols), C.c_int(rows), _ptr(b)), "pslfe_image_bounds")
+        return b
+
+    def set_rgbd(self, slot, kps, desc, depth, cam):
+        """UndistortKeyPoints + ComputeStereoFromRGBD + AssignFeaturesToGrid (src/Frame.cc:105-171) for one frame.
+        depth: CV_32F image in metres."""
+        kps = np.ascontiguousarray(kps, KEYPOINT_DTYPE)
+        desc = np.ascontiguousarray(desc, np.uint8)
+        depth = np.ascontiguousarray(depth, np.float32)
+        cam = np.ascontiguousarray(cam, CAMERA_DTYPE).reshape(1)
+        _check(lib().pslfe_frame_set_rgbd(self._h, C.c_int(slot), _ptr(kps), _ptr(desc), C.c_int(len(kps)), _ptr(depth),
+                                          C.c_int(depth.shape[1]), C.c_int(depth.shape[0]), C.c_int(depth.shape[1]), _ptr(cam)),
+               "pslfe_frame_set_rgbd")
+        self.n[slot] = len(kps)
+
+    def set_from_orb_rgbd(self, orb, d_depth, width, height, cam):
+        """Batched, HBM to HBM: d_depth is a device pointer to [nframes][height][width] float."""
+        cam = np.ascontiguousarray(cam, CAMERA_DTYPE).reshape(1)
+        _check(lib().pslfe_frame_set_from_orb_rgbd(self._h, orb._h, C.c_void_p(int(d_depth)), C.c_int(width), C.c_int(height),
+                                                   _ptr(cam)), "pslfe_frame_set_from_orb_rgbd")
+
+    def fetch(self, slot):
+        """(mvKeysUn, mvDepth, mvuRight) of a slot."""
+        kps = np.zeros(self.cap, KEYPOINT_DTYPE)
+        dep = np.zeros(self.cap, np.float32)
+        ur = np.zeros(self.cap, np.float32)
+        n = C.c_int()
+        _check(lib().pslfe_frame_fetch(self._h, C.c_int(slot), _ptr(kps), _ptr(dep), _ptr(ur), C.c_int(self.cap), C.byref(n)),
+               "pslfe_frame_fetch")
+        self.n[slot] = n.value
+        return kps[:n.value], dep[:n.value], ur[:n.value]
 
     def debug_grid(self, slot):
         start = np.zeros(64 * 48 + 1, np.int32)

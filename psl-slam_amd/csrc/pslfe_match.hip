@@ -64,6 +64,80 @@ __global__ __launch_bounds__(256) void k_frame_import(FrameStore S, const PslKey
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// RGB-D post-processing of a frame's keypoints: Frame::UndistortKeyPoints src/Frame.cc:1062-1092
+// (cv::undistortPoints with P = K: five fixed iterations in double, OpenCV 3.2 Appendix A),
+// Frame::ComputeStereoFromRGBD :1342-1363 and Frame::ComputeImageBounds :1135-1168.
+__device__ __forceinline__ void psl_undistort_point(double u, double v, const PslCamera& C, float* ox, float* oy) {
+    const double fx = C.fx, fy = C.fy, cx = C.cx, cy = C.cy, k1 = C.k1, k2 = C.k2, p1 = C.p1, p2 = C.p2, k3 = C.k3;
+    const double ifx = __ddiv_rn(1., fx), ify = __ddiv_rn(1., fy);
+    double x = __dmul_rn(__dsub_rn(u, cx), ifx), y = __dmul_rn(__dsub_rn(v, cy), ify);
+    const double x0 = x, y0 = y;
+#pragma unroll 1
+    for (int j = 0; j < 5; ++j) {
+        const double xx = __dmul_rn(x, x), yy = __dmul_rn(y, y);
+        const double r2 = __dadd_rn(xx, yy);
+        // (1 + ((k[7]*r2 + k[6])*r2 + k[5])*r2) with k5..k7 = 0 is exactly 1 (r2 is finite and >= 0)
+        const double den = __dadd_rn(1., __dmul_rn(__dadd_rn(__dmul_rn(__dadd_rn(__dmul_rn(k3, r2), k2), r2), k1), r2));
+        const double icdist = __ddiv_rn(1., den);
+        // 2*k[2]*x*y + k[3]*(r2 + 2*x*x) + k[8]*r2 + k[9]*r2*r2 with k8 = k9 = 0 (adding +0 changes nothing but the
+        // sign of a -0 sum, which the subtraction from x0 below cannot observe)
+        const double dX = __dadd_rn(__dmul_rn(__dmul_rn(__dmul_rn(2., p1), x), y), __dmul_rn(p2, __dadd_rn(r2, __dmul_rn(__dmul_rn(2., x), x))));
+        const double dY = __dadd_rn(__dmul_rn(p1, __dadd_rn(r2, __dmul_rn(__dmul_rn(2., y), y))), __dmul_rn(__dmul_rn(__dmul_rn(2., p2), x), y));
+        x = __dmul_rn(__dsub_rn(x0, dX), icdist);
+        y = __dmul_rn(__dsub_rn(y0, dY), icdist);
+    }
+    // RR = K * I; xx = RR00*x + RR01*y + RR02 with RR01 = 0: (fx*x + 0*y) + cx; ww = 1/(0*x + 0*y + 1) = 1
+    const double X = __dadd_rn(__dadd_rn(__dmul_rn(fx, x), __dmul_rn(0., y)), cx);
+    const double Y = __dadd_rn(__dadd_rn(__dmul_rn(0., x), __dmul_rn(fy, y)), cy);
+    *ox = (float)X;
+    *oy = (float)Y;
+}
+
+__global__ void k_image_bounds(PslCamera C, int cols, int rows, float* __restrict__ bounds) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (C.k1 != 0.0f) {
+        float cx[4], cy[4];
+        psl_undistort_point(0., 0., C, &cx[0], &cy[0]);
+        psl_undistort_point((double)(float)cols, 0., C, &cx[1], &cy[1]);
+        psl_undistort_point(0., (double)(float)rows, C, &cx[2], &cy[2]);
+        psl_undistort_point((double)(float)cols, (double)(float)rows, C, &cx[3], &cy[3]);
+        bounds[0] = fminf(cx[0], cx[2]); bounds[2] = fmaxf(cx[1], cx[3]);
+        bounds[1] = fminf(cy[0], cy[1]); bounds[3] = fmaxf(cy[2], cy[3]);
+    } else { bounds[0] = 0.f; bounds[2] = (float)cols; bounds[1] = 0.f; bounds[3] = (float)rows; }
+}
+
+// grid (ceil(cap/256), nframes): keypoints of slot0+blockIdx.y are undistorted in place, depth/uright filled.
+__global__ __launch_bounds__(256) void k_frame_post_rgbd(FrameStore S, float* __restrict__ mvDepth, int slot0, const float* __restrict__ depth,
+                                                          int w, int h, int dstride, size_t dframe, PslCamera C) {
+    const int slot = slot0 + blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= S.meta[slot].n) return;
+    PslKeyPoint* kp = S.kps + (size_t)slot * S.cap + i;
+    const float x = kp->x, y = kp->y;
+    float xu = x, yu = y;
+    if (C.k1 != 0.0f) psl_undistort_point((double)x, (double)y, C, &xu, &yu);
+    const int u = (int)x, v = (int)y;  // imDepth.at<float>(v,u) with float arguments truncates
+    float d = 0.f;
+    if (u >= 0 && u < w && v >= 0 && v < h) d = depth[(size_t)blockIdx.y * dframe + (size_t)v * dstride + u];
+    float dep = -1.f, ur = -1.f;
+    if (d > 0) { dep = d; ur = PSL_FSUB(xu, PSL_FDIV(C.bf, d)); }
+    kp->x = xu; kp->y = yu;
+    mvDepth[(size_t)slot * S.cap + i] = dep;
+    S.uright[(size_t)slot * S.cap + i] = ur;
+}
+
+// meta of slots slot0..slot0+nslots-1 <- grid geometry from the device-side bounds (src/Frame.cc:163-164)
+__global__ void k_frame_meta_bounds(FrameStore S, int slot0, int nslots, const float* __restrict__ bounds) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= nslots) return;
+    FrameMeta m = S.meta[slot0 + k];
+    m.minX = bounds[0]; m.minY = bounds[1];
+    m.invW = PSL_FDIV((float)PSL_GRID_COLS, PSL_FSUB(bounds[2], bounds[0]));
+    m.invH = PSL_FDIV((float)PSL_GRID_ROWS, PSL_FSUB(bounds[3], bounds[1]));
+    S.meta[slot0 + k] = m;
+}
+
 // mGrid[ix][iy] as CSR with cell = ix*48+iy (the order GetFeaturesInArea walks), indices ascending
 // inside a cell (push_back order of AssignFeaturesToGrid).
 __global__ __launch_bounds__(1024) void k_build_grid(FrameStore S, int slot0) {
@@ -457,6 +531,8 @@ struct pslfe_frame {
     uint8_t* d_more = nullptr;   // [max_frames][cap]
     uint32_t* d_topk1 = nullptr; // [PSL_QMAX][4] for the host-pointer entry points
     uint8_t* d_more1 = nullptr;
+    float* d_depth = nullptr;    // [max_frames][cap] mvDepth (RGB-D post-processing)
+    float* d_bounds = nullptr;   // [4] scratch for k_image_bounds
     std::vector<char> slot_set;
 };
 
@@ -535,6 +611,8 @@ int pslfe_frame_create(pslfe_ctx* ctx, int max_keypoints, int max_frames, pslfe_
     A((void**)&f->d_more, F * K);
     A((void**)&f->d_topk1, (size_t)PSL_QMAX * 4 * sizeof(uint32_t));
     A((void**)&f->d_more1, PSL_QMAX);
+    A((void**)&f->d_depth, F * K * sizeof(float));
+    A((void**)&f->d_bounds, 4 * sizeof(float));
     if (e != hipSuccess) {
         pslfe_set_error("pslfe_frame_create: hipMalloc failed: %s", hipGetErrorString(e));
         pslfe_frame_destroy(f);
@@ -553,6 +631,7 @@ void pslfe_frame_destroy(pslfe_frame* f) {
     hipFree(f->S.gidx); hipFree(f->S.meta); hipFree(f->d_q); hipFree(f->d_qdesc); hipFree(f->d_taken);
     hipFree(f->d_match); hipFree(f->d_assigned); hipFree(f->d_nm);
     hipFree(f->d_topk); hipFree(f->d_more); hipFree(f->d_topk1); hipFree(f->d_more1);
+    hipFree(f->d_depth); hipFree(f->d_bounds);
     delete f;
 }
 
@@ -607,6 +686,99 @@ int pslfe_frame_set_from_orb(pslfe_frame* f, pslfe_orb* orb, float min_x, float 
     }
     PSL_HIP(hipGetLastError());
     for (int s = 0; s < nframes; ++s) f->slot_set[s] = 1;
+    return PSLFE_OK;
+}
+
+
+int pslfe_image_bounds(pslfe_frame* f, const PslCamera* cam, int cols, int rows, float* bounds) {
+    PSL_REQUIRE(f && cam && bounds, PSLFE_E_INVALID, "pslfe_image_bounds: NULL argument");
+    PSL_REQUIRE(cols > 0 && rows > 0, PSLFE_E_INVALID, "pslfe_image_bounds: %dx%d", cols, rows);
+    PSL_HIP(hipSetDevice(f->ctx->device));
+    k_image_bounds<<<1, 64, 0, f->ctx->stream>>>(*cam, cols, rows, f->d_bounds);
+    PSL_HIP(hipMemcpyAsync(bounds, f->d_bounds, 4 * sizeof(float), hipMemcpyDeviceToHost, f->ctx->stream));
+    PSL_HIP(hipStreamSynchronize(f->ctx->stream));
+    return PSLFE_OK;
+}
+
+static int frame_post_rgbd(pslfe_frame* f, int slot0, int nslots, const float* d_depth, int w, int h, int dstride, size_t dframe,
+                           const PslCamera* cam) {
+    hipStream_t st = f->ctx->stream;
+    PSL_STAGE_BEGIN(f->ctx, "frame.rgbd");
+    k_image_bounds<<<1, 64, 0, st>>>(*cam, w, h, f->d_bounds);
+    k_frame_meta_bounds<<<(nslots + 255) / 256, 256, 0, st>>>(f->S, slot0, nslots, f->d_bounds);
+    k_frame_post_rgbd<<<dim3((f->cap + 255) / 256, nslots), 256, 0, st>>>(f->S, f->d_depth, slot0, d_depth, w, h, dstride, dframe, *cam);
+    PSL_STAGE_END(f->ctx, "frame.rgbd");
+    {
+        PSL_STAGE_BEGIN(f->ctx, "match.grid");
+        k_build_grid<<<nslots, 1024, 0, st>>>(f->S, slot0);
+        PSL_STAGE_END(f->ctx, "match.grid");
+    }
+    PSL_HIP(hipGetLastError());
+    for (int s = slot0; s < slot0 + nslots; ++s) f->slot_set[s] = 1;
+    return PSLFE_OK;
+}
+
+int pslfe_frame_set_rgbd(pslfe_frame* f, int slot, const PslKeyPoint* kps, const uint8_t* desc, int n, const float* depth, int width,
+                         int height, int depth_stride, const PslCamera* cam) {
+    PSL_REQUIRE(f && cam && depth && (n == 0 || (kps && desc)), PSLFE_E_INVALID, "pslfe_frame_set_rgbd: NULL argument");
+    PSL_REQUIRE(slot >= 0 && slot < f->max_frames, PSLFE_E_INVALID, "pslfe_frame_set_rgbd: slot %d of %d", slot, f->max_frames);
+    PSL_REQUIRE(n >= 0 && n <= f->cap, PSLFE_E_CAPACITY, "pslfe_frame_set_rgbd: %d keypoints, capacity %d", n, f->cap);
+    PSL_REQUIRE(width > 0 && height > 0 && depth_stride >= width, PSLFE_E_INVALID, "pslfe_frame_set_rgbd: depth %dx%d stride %d", width, height, depth_stride);
+    PSL_HIP(hipSetDevice(f->ctx->device));
+    hipStream_t st = f->ctx->stream;
+    const size_t o = (size_t)slot * f->cap;
+    float* d_img = nullptr;
+    PSL_HIP(hipMalloc((void**)&d_img, (size_t)height * depth_stride * sizeof(float)));
+    hipError_t e = hipMemcpyAsync(d_img, depth, (size_t)height * depth_stride * sizeof(float), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess && n > 0) e = hipMemcpyAsync(f->S.kps + o, kps, (size_t)n * sizeof(PslKeyPoint), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess && n > 0) e = hipMemcpyAsync(f->S.desc + o * 32, desc, (size_t)n * 32, hipMemcpyHostToDevice, st);
+    FrameMeta m = {};
+    m.n = n;
+    if (e == hipSuccess) e = hipMemcpyAsync(f->S.meta + slot, &m, sizeof(m), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    int rc = PSLFE_OK;
+    if (e != hipSuccess) { pslfe_set_error("pslfe_frame_set_rgbd: H2D: %s", hipGetErrorString(e)); rc = PSLFE_E_HIP; }
+    if (!rc) rc = frame_post_rgbd(f, slot, 1, d_img, width, height, depth_stride, 0, cam);
+    hipStreamSynchronize(st);
+    hipFree(d_img);
+    return rc;
+}
+
+int pslfe_frame_set_from_orb_rgbd(pslfe_frame* f, pslfe_orb* orb, const float* d_depth, int width, int height, const PslCamera* cam) {
+    PSL_REQUIRE(f && orb && d_depth && cam, PSLFE_E_INVALID, "pslfe_frame_set_from_orb_rgbd: NULL argument");
+    PSL_REQUIRE(width > 0 && height > 0, PSLFE_E_INVALID, "pslfe_frame_set_from_orb_rgbd: depth %dx%d", width, height);
+    const PslKeyPoint* okps; const uint8_t* odesc; const int* ocnt; int ocap, nframes; pslfe_ctx* octx;
+    int rc = pslfe_orb_internal_last(orb, &okps, &odesc, &ocnt, &ocap, &nframes, &octx);
+    if (rc) return rc;
+    PSL_REQUIRE(octx == f->ctx, PSLFE_E_INVALID, "pslfe_frame_set_from_orb_rgbd: handles belong to different contexts");
+    PSL_REQUIRE(nframes <= f->max_frames, PSLFE_E_CAPACITY, "pslfe_frame_set_from_orb_rgbd: %d frames, %d slots", nframes, f->max_frames);
+    PSL_REQUIRE(ocap <= f->cap, PSLFE_E_CAPACITY, "pslfe_frame_set_from_orb_rgbd: extractor capacity %d > frame capacity %d", ocap, f->cap);
+    PSL_HIP(hipSetDevice(f->ctx->device));
+    {
+        PSL_STAGE_BEGIN(f->ctx, "match.grid");
+        k_frame_import<<<nframes, 256, 0, f->ctx->stream>>>(f->S, okps, odesc, ocnt, ocap, 0.f, 0.f, 1.f, 1.f);
+        PSL_STAGE_END(f->ctx, "match.grid");
+    }
+    return frame_post_rgbd(f, 0, nframes, d_depth, width, height, width, (size_t)width * height, cam);
+}
+
+int pslfe_frame_fetch(pslfe_frame* f, int slot, PslKeyPoint* kps_un, float* depth, float* uright, int cap, int* n) {
+    PSL_REQUIRE(f && n, PSLFE_E_INVALID, "pslfe_frame_fetch: NULL argument");
+    PSL_REQUIRE(slot >= 0 && slot < f->max_frames && f->slot_set[slot], PSLFE_E_STATE, "pslfe_frame_fetch: slot %d not set", slot);
+    PSL_HIP(hipSetDevice(f->ctx->device));
+    hipStream_t st = f->ctx->stream;
+    FrameMeta m;
+    PSL_HIP(hipMemcpyAsync(&m, f->S.meta + slot, sizeof(m), hipMemcpyDeviceToHost, st));
+    PSL_HIP(hipStreamSynchronize(st));
+    *n = m.n;
+    PSL_REQUIRE(m.n <= cap, PSLFE_E_CAPACITY, "pslfe_frame_fetch: %d keypoints, capacity %d", m.n, cap);
+    const size_t o = (size_t)slot * f->cap;
+    if (m.n > 0) {
+        if (kps_un) PSL_HIP(hipMemcpyAsync(kps_un, f->S.kps + o, (size_t)m.n * sizeof(PslKeyPoint), hipMemcpyDeviceToHost, st));
+        if (depth) PSL_HIP(hipMemcpyAsync(depth, f->d_depth + o, (size_t)m.n * sizeof(float), hipMemcpyDeviceToHost, st));
+        if (uright) PSL_HIP(hipMemcpyAsync(uright, f->S.uright + o, (size_t)m.n * sizeof(float), hipMemcpyDeviceToHost, st));
+        PSL_HIP(hipStreamSynchronize(st));
+    }
     return PSLFE_OK;
 }
 

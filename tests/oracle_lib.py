@@ -329,3 +329,56 @@ def line_search_by_projection(kls, desc, eq, bounds, queries, qdesc, mode=0, dir
         [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p]
     n = L.pso_line_search_by_projection(_p(k), _p(d), _p(e), _p(d3), len(k), *bounds, _p(q), _p(qd), len(q), _p(tk), mode, nnratio, _p(match), _p(asg))
     return n, match[:len(q)], asg[:len(k)]
+
+
+CAMERA_DTYPE = np.dtype([(k, "<f4") for k in ("fx", "fy", "cx", "cy", "k1", "k2", "p1", "p2", "k3", "bf")])
+
+
+def rgb_to_gray(rgb, is_rgb=True):
+    L = load()
+    rgb = np.ascontiguousarray(rgb, np.uint8)
+    h, w = rgb.shape[:2]
+    gray = np.zeros((h, w), np.uint8)
+    L.pso_rgb_to_gray.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    L.pso_rgb_to_gray(_p(rgb), w, h, 3 * w, 1 if is_rgb else 0, _p(gray))
+    return gray
+
+
+def depth_to_float(depth, factor):
+    L = load()
+    depth = np.ascontiguousarray(depth, np.uint16)
+    out = np.zeros(depth.shape, np.float32)
+    L.pso_depth_to_float.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_void_p]
+    L.pso_depth_to_float(_p(depth), depth.size, factor, _p(out))
+    return out
+
+
+def _cam_arrays(cam):
+    cam = np.asarray(cam, CAMERA_DTYPE).reshape(())
+    K = np.array([cam["fx"], cam["fy"], cam["cx"], cam["cy"]], np.float32)
+    dist = np.array([cam["k1"], cam["k2"], cam["p1"], cam["p2"], cam["k3"]], np.float32)
+    return K, dist, float(cam["bf"])
+
+
+def image_bounds(cam, cols, rows):
+    L = load()
+    K, dist, _ = _cam_arrays(cam)
+    b = np.zeros(4, np.float32)
+    L.pso_image_bounds.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.pso_image_bounds(cols, rows, _p(K), _p(dist), _p(b))
+    return b
+
+
+def frame_post_rgbd(kps, depth, cam):
+    L = load()
+    kps = np.ascontiguousarray(kps, KEYPOINT_DTYPE)
+    depth = np.ascontiguousarray(depth, np.float32)
+    K, dist, bf = _cam_arrays(cam)
+    n = len(kps)
+    un = np.zeros(max(n, 1), KEYPOINT_DTYPE)
+    dep = np.zeros(max(n, 1), np.float32)
+    ur = np.zeros(max(n, 1), np.float32)
+    L.pso_frame_post_rgbd.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_float,
+                                      C.c_void_p, C.c_void_p, C.c_void_p]
+    L.pso_frame_post_rgbd(_p(kps), n, _p(depth), depth.shape[1], depth.shape[0], depth.shape[1], _p(K), _p(dist), bf, _p(un), _p(dep), _p(ur))
+    return un[:n], dep[:n], ur[:n]

@@ -138,3 +138,71 @@ def test_line_grid_and_area_small():
     q["radius"], q["th_cos"], q["vx"], q["vy"], q["length"], q["blocks"] = 6.0, 0.96, [200, 0], [0, 200], 200.0, 1
     n, match, asg = oracle_lib.line_search_by_projection(kl, desc, eq, bounds, q, np.zeros((2, 32), np.uint8), 0)
     assert n == 1 and list(match) == [0, -1] and list(asg) == [0]
+
+
+# ---- frame post-processing (gray, depth, undistortion, stereo-from-RGBD) ---------------------------------
+TUM1 = (517.306408, 516.469215, 318.643040, 255.313989, 0.262383, -0.953104, -0.005358, 0.002628, 1.163314, 40.0)
+
+
+def _cam(vals):
+    c = np.zeros((), oracle_lib.CAMERA_DTYPE)
+    for k, v in zip(oracle_lib.CAMERA_DTYPE.names, vals):
+        c[k] = np.float32(v)
+    return c
+
+
+def test_rgb_to_gray_matches_float_formula_within_one():
+    rng = np.random.default_rng(1)
+    rgb = rng.integers(0, 256, (48, 64, 3), dtype=np.uint8)
+    g = oracle_lib.rgb_to_gray(rgb, True).astype(np.float64)
+    f = rgb[..., 0] * 0.299 + rgb[..., 1] * 0.587 + rgb[..., 2] * 0.114
+    assert np.abs(g - f).max() <= 0.51
+    gb = oracle_lib.rgb_to_gray(rgb[..., ::-1].copy(), False)
+    np.testing.assert_array_equal(gb, g.astype(np.uint8))
+    assert oracle_lib.rgb_to_gray(np.full((1, 1, 3), 255, np.uint8))[0, 0] == 255  # 4899+9617+1868 == 1<<14
+
+
+def test_depth_to_float_is_float_product():
+    d = np.array([0, 1, 5000, 65535], np.uint16)
+    f = np.float32(1.0 / 5000.0)
+    np.testing.assert_array_equal(oracle_lib.depth_to_float(d, f), d.astype(np.float32) * f)
+
+
+def test_undistort_inverts_the_distortion_model():
+    """Independent check of the five-iteration undistortion: distort ideal points with the forward
+    radial-tangential model (float64 numpy), undistort with the oracle, recover the ideal points."""
+    cam = _cam(TUM1)
+    fx, fy, cx, cy, k1, k2, p1, p2, k3, _ = [float(np.float32(v)) for v in TUM1]
+    rng = np.random.default_rng(2)
+    ideal = np.stack([rng.uniform(40, 600, 400), rng.uniform(40, 440, 400)], 1)
+    x, y = (ideal[:, 0] - cx) / fx, (ideal[:, 1] - cy) / fy
+    r2 = x * x + y * y
+    rad = 1 + k1 * r2 + k2 * r2 * r2 + k3 * r2 ** 3
+    xd = x * rad + 2 * p1 * x * y + p2 * (r2 + 2 * x * x)
+    yd = y * rad + p1 * (r2 + 2 * y * y) + 2 * p2 * x * y
+    kps = np.zeros(400, oracle_lib.KEYPOINT_DTYPE)
+    kps["x"], kps["y"] = xd * fx + cx, yd * fy + cy
+    depth = np.full((480, 640), 2.0, np.float32)
+    inside = (kps["x"] >= 0) & (kps["x"] < 640) & (kps["y"] >= 0) & (kps["y"] < 480)
+    kps = kps[inside]
+    un, dep, ur = oracle_lib.frame_post_rgbd(kps, depth, cam)
+    err = np.hypot(un["x"] - ideal[inside, 0], un["y"] - ideal[inside, 1])
+    assert err.max() < 0.05  # five fixed-point iterations, not a converged solve
+    np.testing.assert_array_equal(dep, np.float32(2.0))
+    np.testing.assert_array_equal(ur, un["x"] - np.float32(40.0) / np.float32(2.0))
+
+
+def test_image_bounds_and_zero_distortion_identity():
+    cam0 = _cam((535.4, 539.2, 320.1, 247.6, 0, 0, 0, 0, 0, 40.0))
+    np.testing.assert_array_equal(oracle_lib.image_bounds(cam0, 640, 480), [0, 0, 640, 480])
+    b = oracle_lib.image_bounds(_cam(TUM1), 640, 480)
+    # k1 > 0: distorted radii exceed ideal ones, so the undistorted corners lie inside the image
+    assert 0 < b[0] < 30 and 0 < b[1] < 30 and 600 < b[2] < 640 and 450 < b[3] < 480
+    kps = np.zeros(3, oracle_lib.KEYPOINT_DTYPE)
+    kps["x"], kps["y"] = [10.7, 300.2, 639.9], [5.5, 200.9, 479.9]
+    depth = np.zeros((480, 640), np.float32)
+    depth[200, 300] = 1.5
+    un, dep, ur = oracle_lib.frame_post_rgbd(kps, depth, cam0)
+    assert un.tobytes() == kps.tobytes()
+    np.testing.assert_array_equal(dep, [-1, 1.5, -1])
+    np.testing.assert_array_equal(ur, np.array([-1, np.float32(300.2) - np.float32(40.0) / np.float32(1.5), -1], np.float32))
