@@ -98,6 +98,91 @@ __global__ __launch_bounds__(256) void k_pyr_resize(OrbParams P, FrameSrc S, int
     *reinterpret_cast<uint32_t*>(dst + x4) = packed;
 }
 
+// Same arithmetic, source staged through LDS: a workgroup produces a 64 x 16 block of the level and first
+// copies the source rectangle it needs (<= PSL_PYR_TR rows of <= PSL_PYR_TD dwords) with coalesced dword
+// loads; the 16 taps of a thread then come from LDS instead of 16 scattered byte loads from HBM/L2.
+#define PSL_PYR_TD 40   // tile pitch in dwords (scale factors up to ~2.3)
+#define PSL_PYR_TR 40   // tile rows
+__global__ __launch_bounds__(256) void k_pyr_resize_tiled(OrbParams P, FrameSrc S, int level,
+                                                           const int* __restrict__ xofs, const short2* __restrict__ alpha,
+                                                           const int* __restrict__ yofs, const short2* __restrict__ beta) {
+    __shared__ uint32_t s_tile[PSL_PYR_TR * PSL_PYR_TD];
+    const OrbLevelP L = P.lv[level];
+    const int frame = blockIdx.z, tid = threadIdx.x;
+    const int x0 = blockIdx.x * 64, y0 = blockIdx.y * 16;
+    int spitch;
+    const uint8_t* src = psl_level_ptr(P, S, level - 1, frame, &spitch);
+    const int sw = P.lv[level - 1].w, sh = P.lv[level - 1].h;
+    // source rectangle of this block (tables are non-decreasing)
+    const int xe = min(x0 + 63, L.w - 1), ye = min(y0 + 15, L.h - 1);
+    const int cfirst = xofs[min(x0, L.w - 1)], clast = min(xofs[xe] + 1, sw - 1);
+    const int rfirst = min(max(yofs[y0], 0), sh - 1), rlast = min(max(yofs[ye] + 1, 0), sh - 1);
+    const int cbase = cfirst & ~3;
+    const int ndw = ((clast - cbase) >> 2) + 1, nrows = rlast - rfirst + 1;
+    // dword staging needs 4-byte aligned rows whose last dword stays inside the row pitch
+    const bool staged = ndw <= PSL_PYR_TD && nrows <= PSL_PYR_TR && cfirst >= 0 &&
+                        ((reinterpret_cast<uintptr_t>(src) | (uintptr_t)spitch) & 3) == 0 && cbase + ndw * 4 <= spitch;
+    if (staged) {
+        for (int k = tid; k < nrows * ndw; k += 256) {
+            const int r = k / ndw, d = k - r * ndw;
+            s_tile[r * PSL_PYR_TD + d] = *reinterpret_cast<const uint32_t*>(src + (size_t)(rfirst + r) * spitch + cbase + d * 4);
+        }
+    }
+    __syncthreads();
+    const int dy = y0 + (tid >> 4);
+    const int x4 = x0 + (tid & 15) * 4;
+    if (dy >= L.h || x4 >= L.pitch) return;
+    uint8_t* dst = S.pyr + (size_t)frame * S.pyr_fstride + L.img_off + (size_t)dy * L.pitch;
+    int sy0 = yofs[dy], sy1 = sy0 + 1;
+    sy0 = sy0 < 0 ? 0 : (sy0 >= sh ? sh - 1 : sy0);
+    sy1 = sy1 < 0 ? 0 : (sy1 >= sh ? sh - 1 : sy1);
+    const short2 b = beta[dy];
+    int sx[4];
+    short2 a[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        int dx = x4 + j;
+        dx = dx < L.w ? dx : L.w - 1;  // padding columns repeat the last pixel
+        sx[j] = xofs[dx];
+        a[j] = alpha[dx];
+    }
+    uint32_t packed = 0;
+    if (staged) {
+        const uint8_t* t0 = reinterpret_cast<const uint8_t*>(s_tile) + (sy0 - rfirst) * (PSL_PYR_TD * 4) - cbase;
+        const uint8_t* t1 = reinterpret_cast<const uint8_t*>(s_tile) + (sy1 - rfirst) * (PSL_PYR_TD * 4) - cbase;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int h0, h1;
+            if (sx[j] + 1 < sw) {
+                h0 = t0[sx[j]] * a[j].x + t0[sx[j] + 1] * a[j].y;
+                h1 = t1[sx[j]] * a[j].x + t1[sx[j] + 1] * a[j].y;
+            } else {
+                h0 = t0[sx[j]] * 2048;
+                h1 = t1[sx[j]] * 2048;
+            }
+            const int v = ((((int)b.x * (h0 >> 4)) >> 16) + (((int)b.y * (h1 >> 4)) >> 16) + 2) >> 2;
+            packed |= (uint32_t)(v & 0xff) << (8 * j);
+        }
+    } else {
+        const uint8_t* r0 = src + (size_t)sy0 * spitch;
+        const uint8_t* r1 = src + (size_t)sy1 * spitch;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int h0, h1;
+            if (sx[j] + 1 < sw) {
+                h0 = r0[sx[j]] * a[j].x + r0[sx[j] + 1] * a[j].y;
+                h1 = r1[sx[j]] * a[j].x + r1[sx[j] + 1] * a[j].y;
+            } else {
+                h0 = r0[sx[j]] * 2048;
+                h1 = r1[sx[j]] * 2048;
+            }
+            const int v = ((((int)b.x * (h0 >> 4)) >> 16) + (((int)b.y * (h1 >> 4)) >> 16) + 2) >> 2;
+            packed |= (uint32_t)(v & 0xff) << (8 * j);
+        }
+    }
+    *reinterpret_cast<uint32_t*>(dst + x4) = packed;
+}
+
 // ---------------------------------------------------------------------------------------------
 // FAST-9/16 per cell with score NMS and the per-cell threshold fallback (src/ORBextractor.cc:789-829
 // around cv::FAST, Appendix A.6).  One workgroup = one cell of one level of one frame.
@@ -268,6 +353,207 @@ __global__ __launch_bounds__(256, 8) void k_fast_cells(OrbParams P, FrameSrc S, 
             const uint32_t s = s_score[(y + 1) * PSL_FAST_SP + x + 1];
             if (pos < P.cellcap)
                 out[pos] = (uint32_t)(x + 3 + j * L.wCell) | ((uint32_t)(y + 3 + i * L.hCell) << 12) | (s << 24);
+        }
+    }
+    if (tid == 0) *out_cnt = total < P.cellcap ? total : P.cellcap;
+}
+
+// k_fast_cells4: same results as k_fast_cells, four horizontally adjacent pixels per thread.
+//   * the tile is stored with interior column 0 at a dword boundary (tile byte = 1 + tile x), shifting the
+//     global dwords with v_alignbyte on the way in, so the 9 ring samples of the quick test for 4 pixels come
+//     from 11 aligned LDS dword reads (+ 6 alignbyte) instead of 36 byte reads;
+//   * index arithmetic, ballots and compaction are paid once per 4 pixels; a typical 31 x 31 cell is one pass;
+//   * the NMS pass reads one score dword per 4 pixels and stops there when it is zero (almost always).
+#define PSL_FAST4_TP 76   // tile pitch (bytes): 1 + (64 + 6) + slack, multiple of 4
+#define PSL_FAST4_SP 72   // score pitch (bytes): interior x at byte 4 + x
+__device__ __forceinline__ uint32_t psl_alignbyte(uint32_t hi, uint32_t lo, uint32_t sh) { return __builtin_amdgcn_alignbyte(hi, lo, sh); }
+
+__global__ __launch_bounds__(256, 8) void k_fast_cells4(OrbParams P, FrameSrc S, int* __restrict__ cellcnt,
+                                                      uint32_t* __restrict__ cellcand) {
+    __shared__ __attribute__((aligned(16))) uint32_t s_tile32[(PSL_MAXCELL + 6) * (PSL_FAST4_TP / 4) + 4];
+    __shared__ __attribute__((aligned(16))) uint32_t s_score32[(PSL_MAXCELL + 2) * (PSL_FAST4_SP / 4)];
+    __shared__ int s_cnt[2][16];  // survivors per (pass, wave) at iniTh / minTh
+    __shared__ int s_off[2][17];
+    __shared__ uint16_t s_list[PSL_MAXCELL * PSL_MAXCELL];  // y << 6 | x of pixels that pass the quick test
+    __shared__ int s_nlist;
+    uint8_t* s_tile = reinterpret_cast<uint8_t*>(s_tile32);
+    uint8_t* s_score = reinterpret_cast<uint8_t*>(s_score32);
+
+    const int cell = blockIdx.x, frame = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int level = 0;
+    while (level + 1 < P.nlevels && cell >= P.lv[level + 1].cell_off) ++level;
+    const OrbLevelP L = P.lv[level];
+    const int ci = cell - L.cell_off;
+    const int i = ci / L.nCols, j = ci - i * L.nCols;
+    int* out_cnt = cellcnt + (size_t)frame * P.ncells + cell;
+    uint32_t* out = cellcand + ((size_t)frame * P.ncells + cell) * P.cellcap;
+
+    const int iniY = PSL_EDGE + i * L.hCell, iniX = PSL_EDGE + j * L.wCell;  // src/ORBextractor.cc:789-806
+    int maxY = iniY + L.hCell + 6, maxX = iniX + L.wCell + 6;
+    if (maxY > L.maxBY) maxY = L.maxBY;
+    if (maxX > L.maxBX) maxX = L.maxBX;
+    const int tw = maxX - iniX, th = maxY - iniY;
+    if (iniY >= L.maxBY - 3 || iniX >= L.maxBX - 6 || tw < 7 || th < 7) {
+        if (tid == 0) *out_cnt = 0;
+        return;
+    }
+    const int iw = tw - 6, ih = th - 6;
+
+    int pitch;
+    const uint8_t* img = psl_level_ptr(P, S, level, frame, &pitch);
+    // LDS tile byte (1 + x) of row y = image pixel (iniX + x, iniY + y); dword d of a row = image bytes
+    // iniX - 1 + 4d .. + 3, assembled from the two aligned global dwords that hold them
+    const bool aligned4 = ((reinterpret_cast<uintptr_t>(img) | (uintptr_t)pitch) & 3) == 0 && iniX >= 4 && maxX + 8 <= pitch;
+    const int ndw = (tw + 4) >> 2;  // <= 18
+    if (aligned4) {
+        const int gx0 = (iniX - 1) & ~3;
+        const uint32_t sh = (uint32_t)((iniX - 1) & 3);
+        for (int k = tid; k < th * ndw; k += 256) {
+            const int y = k / ndw, d = k - y * ndw;
+            const uint32_t* g = reinterpret_cast<const uint32_t*>(img + (size_t)(iniY + y) * pitch + gx0) + d;
+            s_tile32[y * (PSL_FAST4_TP / 4) + d] = psl_alignbyte(g[1], g[0], sh);
+        }
+    } else {
+        for (int y = wave; y < th; y += 4) {
+            const uint8_t* row = img + (size_t)(iniY + y) * pitch + iniX;
+            for (int x = lane; x < tw; x += 64) s_tile[y * PSL_FAST4_TP + 1 + x] = row[x];
+        }
+    }
+    for (int k = tid; k < (ih + 2) * (PSL_FAST4_SP / 4); k += 256) s_score32[k] = 0;
+    if (tid < 32) (&s_cnt[0][0])[tid] = 0;
+    if (tid == 0) s_nlist = 0;
+    __syncthreads();
+
+    const int ng = (iw + 3) >> 2;            // groups of 4 pixels per row, <= 16
+    const int nitems = ng * ih;              // <= 1024
+    const int npass = (nitems + 255) >> 8;   // <= 4
+    const uint32_t magic = (1048576u + (uint32_t)ng - 1u) / (uint32_t)ng;  // idx / ng == (idx * magic) >> 20 for idx < 4096
+    const int minTh = P.minTh, iniTh = P.iniTh;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    // Quick reject, see k_fast_cells.
+    for (int p = 0; p < npass; ++p) {
+        const int idx = p * 256 + tid;
+        uint32_t m4 = 0;
+        int y = 0, g = 0;
+        if (idx < nitems) {
+            y = (int)(((uint32_t)idx * magic) >> 20);
+            g = idx - y * ng;
+            // centre of pixel 4g + jj: tile byte 4(g+1) + jj of tile row y + 3
+            const uint32_t* r = &s_tile32[(y + 3) * (PSL_FAST4_TP / 4) + g];
+            const uint32_t m0 = r[0], m1 = r[1], m2 = r[2];
+            const uint32_t C = m1, R12 = psl_alignbyte(m1, m0, 1), R4 = psl_alignbyte(m2, m1, 3);
+            const uint32_t R0 = r[3 * (PSL_FAST4_TP / 4) + 1], R8 = r[-3 * (PSL_FAST4_TP / 4) + 1];
+            const uint32_t* rp = r + 2 * (PSL_FAST4_TP / 4);
+            const uint32_t* rm = r - 2 * (PSL_FAST4_TP / 4);
+            const uint32_t p0 = rp[0], p1 = rp[1], p2 = rp[2], q0 = rm[0], q1 = rm[1], q2 = rm[2];
+            const uint32_t R14 = psl_alignbyte(p1, p0, 2), R2 = psl_alignbyte(p2, p1, 2);
+            const uint32_t R10 = psl_alignbyte(q1, q0, 2), R6 = psl_alignbyte(q2, q1, 2);
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const int sft = 8 * jj;
+                const int c = (C >> sft) & 255, hi = c + minTh, lo = c - minTh;
+                const int r0 = (R0 >> sft) & 255, r8 = (R8 >> sft) & 255, r4 = (R4 >> sft) & 255, r12 = (R12 >> sft) & 255;
+                const int r2 = (R2 >> sft) & 255, r10 = (R10 >> sft) & 255, r6 = (R6 >> sft) & 255, r14 = (R14 >> sft) & 255;
+                const int bmin = min(min(max(r0, r8), max(r4, r12)), min(max(r2, r10), max(r6, r14)));
+                const int dmax = max(max(min(r0, r8), min(r4, r12)), max(min(r2, r10), min(r6, r14)));
+                const bool pass = ((bmin > hi) | (dmax < lo)) & (4 * g + jj < iw);
+                m4 |= (uint32_t)pass << jj;
+            }
+        }
+        // order inside s_list is irrelevant: one slot range per (wave, jj)
+        const unsigned long long b0 = __ballot(m4 & 1), b1 = __ballot(m4 & 2), b2 = __ballot(m4 & 4), b3 = __ballot(m4 & 8);
+        const int n0 = __popcll(b0), n1 = __popcll(b1), n2 = __popcll(b2), n3 = __popcll(b3);
+        const int tot = n0 + n1 + n2 + n3;
+        if (tot) {
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&s_nlist, tot);
+            base = __shfl(base, 0);
+            const uint32_t e = (uint32_t)(y << 6) | (uint32_t)(4 * g);
+            if (m4 & 1) s_list[base + __popcll(b0 & lt)] = (uint16_t)e;
+            if (m4 & 2) s_list[base + n0 + __popcll(b1 & lt)] = (uint16_t)(e + 1);
+            if (m4 & 4) s_list[base + n0 + n1 + __popcll(b2 & lt)] = (uint16_t)(e + 2);
+            if (m4 & 8) s_list[base + n0 + n1 + n2 + __popcll(b3 & lt)] = (uint16_t)(e + 3);
+        }
+    }
+    __syncthreads();
+    const int nlist = s_nlist;
+    for (int k = tid; k < nlist; k += 256) {
+        const int e = s_list[k];
+        const int y = e >> 6, x = e & 63;
+        int s = psl_fast_score(&s_tile[(y + 3) * PSL_FAST4_TP + x + 4], PSL_FAST4_TP);
+        s = s < minTh ? 0 : (s > 255 ? 255 : s);
+        s_score[(y + 1) * PSL_FAST4_SP + x + 4] = (uint8_t)s;
+    }
+    __syncthreads();
+
+    uint32_t keep_ini = 0, keep_min = 0;  // bits 4p..4p+3: pixels of this thread's item of pass p that survive
+    for (int p = 0; p < npass; ++p) {
+        const int idx = p * 256 + tid;
+        uint32_t f_min = 0, f_ini = 0;
+        if (idx < nitems) {
+            const int y = (int)(((uint32_t)idx * magic) >> 20), g = idx - y * ng;
+            const uint32_t* r = &s_score32[(y + 1) * (PSL_FAST4_SP / 4) + g];
+            const uint32_t C = r[1];
+            if (C) {
+                const uint32_t* ru = r - (PSL_FAST4_SP / 4);
+                const uint32_t* rd = r + (PSL_FAST4_SP / 4);
+                const uint32_t u0 = ru[0], u1 = ru[1], u2 = ru[2], m0 = r[0], m2 = r[2], d0 = rd[0], d1 = rd[1], d2 = rd[2];
+                const uint32_t UL = psl_alignbyte(u1, u0, 3), UR = psl_alignbyte(u2, u1, 1);
+                const uint32_t ML = psl_alignbyte(C, m0, 3), MR = psl_alignbyte(m2, C, 1);
+                const uint32_t DL = psl_alignbyte(d1, d0, 3), DR = psl_alignbyte(d2, d1, 1);
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const int sft = 8 * jj;
+                    const int s = (C >> sft) & 255;
+                    const int m = max(max(max((int)((UL >> sft) & 255), (int)((u1 >> sft) & 255)), max((int)((UR >> sft) & 255), (int)((ML >> sft) & 255))),
+                                      max(max((int)((MR >> sft) & 255), (int)((DL >> sft) & 255)), max((int)((d1 >> sft) & 255), (int)((DR >> sft) & 255))));
+                    const bool fm = s > m;  // s == 0 never passes
+                    f_min |= (uint32_t)fm << jj;
+                    f_ini |= (uint32_t)(fm && s >= iniTh) << jj;
+                }
+            }
+        }
+        int c_ini = __popc(f_ini), c_min = __popc(f_min);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { c_ini += __shfl_xor(c_ini, o); c_min += __shfl_xor(c_min, o); }
+        if (lane == 0) { s_cnt[0][p * 4 + wave] = c_ini; s_cnt[1][p * 4 + wave] = c_min; }
+        keep_ini |= f_ini << (4 * p);
+        keep_min |= f_min << (4 * p);
+    }
+    __syncthreads();
+    if (tid < 32) {  // exclusive scan of the 16 (pass, wave) counts, both thresholds
+        const int t = tid >> 4, k = tid & 15;
+        const int v = s_cnt[t][k];
+        int inc = v;
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) { const int u = __shfl_up(inc, o, 16); if (k >= o) inc += u; }
+        s_off[t][k] = inc - v;
+        if (k == 15) s_off[t][16] = inc;
+    }
+    __syncthreads();
+    const int use = s_off[0][16] > 0 ? 0 : 1;  // retry at minTh only if iniTh found nothing (:812-816)
+    const int total = s_off[use][16];
+    const uint32_t keep = use == 0 ? keep_ini : keep_min;
+    for (int p = 0; p < npass; ++p) {
+        const uint32_t f = (keep >> (4 * p)) & 15;
+        // raster order: items in index order, pixels of an item left to right
+        const int n = __popc(f);
+        int inc = n;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(inc, o); if (lane >= o) inc += u; }
+        if (f) {
+            const int idx = p * 256 + tid;
+            const int y = (int)(((uint32_t)idx * magic) >> 20), g = idx - y * ng;
+            int pos = s_off[use][p * 4 + wave] + inc - n;
+            const uint32_t sc = s_score32[(y + 1) * (PSL_FAST4_SP / 4) + g + 1];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj)
+                if ((f >> jj) & 1) {
+                    if (pos < P.cellcap)
+                        out[pos] = (uint32_t)(4 * g + jj + 3 + j * L.wCell) | ((uint32_t)(y + 3 + i * L.hCell) << 12) | (((sc >> (8 * jj)) & 255) << 24);
+                    ++pos;
+                }
         }
     }
     if (tid == 0) *out_cnt = total < P.cellcap ? total : P.cellcap;
@@ -602,10 +888,14 @@ __constant__ int8_t c_orb_pattern[1024] = {
 #include "orb_pattern.inc"
 };
 
+#define PSL_DESC_PD 11  // LDS pitch of the descriptor patch in dwords: 37 + 3 alignment bytes -> 10, odd pitch
+#define PSL_ORI_PD 9    // LDS pitch of the orientation patch in dwords: 31 + 3 alignment bytes -> 9
 __global__ __launch_bounds__(256) void k_orient_describe(OrbParams P, FrameSrc S, const uint8_t* __restrict__ blur,
                                                           size_t blur_fstride, const uint32_t* __restrict__ lvlkp,
                                                           const int* __restrict__ lvlcnt, PslKeyPoint* __restrict__ kps,
                                                           uint8_t* __restrict__ desc, int* __restrict__ counts) {
+    __shared__ uint32_t s_patch[4][37 * PSL_DESC_PD];
+    __shared__ uint32_t s_ori[4][31 * PSL_ORI_PD];
     const int frame = blockIdx.y;
     const int lane = threadIdx.x & 63;
     const int slot = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -625,6 +915,47 @@ __global__ __launch_bounds__(256) void k_orient_describe(OrbParams P, FrameSrc S
     int pitch;
     const uint8_t* img = psl_level_ptr(P, S, level, frame, &pitch);
 
+    // One memory round trip for everything the keypoint needs: the 31 x 31 patch of the level image (orientation)
+    // and the 37 x 37 patch of the blurred level (the 512 rBRIEF samples lie within radius 18.4 of the keypoint, so
+    // the rotated, rounded offsets stay in [-18, 18]) are fetched with row-coalesced dword loads that are all in
+    // flight together, then parked in LDS; the scattered per-lane samples come from there.
+    const uint8_t* bl = blur + (size_t)frame * blur_fstride + L.blur_off;
+    uint32_t* patch = s_patch[threadIdx.x >> 6];
+    uint32_t* ori = s_ori[threadIdx.x >> 6];
+    const int pc0 = (cx - 18) & ~3, pr0 = cy - 18;  // blurred patch origin (dword-aligned column)
+    const int oc0 = (cx - 15) & ~3, or0 = cy - 15;  // orientation patch origin
+    const bool ori_dw = ((reinterpret_cast<uintptr_t>(img) | (uintptr_t)pitch) & 3) == 0 && oc0 + 4 * PSL_ORI_PD <= pitch;
+    uint32_t pv[7], ov[5];
+#pragma unroll
+    for (int t = 0; t < 7; ++t) {
+        const int k = lane + 64 * t;
+        const int r = k / PSL_DESC_PD, d = k - r * PSL_DESC_PD;
+        int gy = pr0 + r;
+        gy = gy < 0 ? 0 : (gy >= L.h ? L.h - 1 : gy);  // never sampled; keeps the loads inside the level
+        const int gx = min(pc0 + d * 4, L.pitch - 4);
+        pv[t] = k < 37 * PSL_DESC_PD ? *reinterpret_cast<const uint32_t*>(bl + (size_t)gy * L.pitch + gx) : 0u;
+    }
+    if (ori_dw) {
+#pragma unroll
+        for (int t = 0; t < 5; ++t) {
+            const int k = lane + 64 * t;
+            const int r = k / PSL_ORI_PD, d = k - r * PSL_ORI_PD;
+            ov[t] = k < 31 * PSL_ORI_PD ? *reinterpret_cast<const uint32_t*>(img + (size_t)(or0 + r) * pitch + oc0 + d * 4) : 0u;
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 7; ++t) { const int k = lane + 64 * t; if (k < 37 * PSL_DESC_PD) patch[k] = pv[t]; }
+    if (ori_dw) {
+#pragma unroll
+        for (int t = 0; t < 5; ++t) { const int k = lane + 64 * t; if (k < 31 * PSL_ORI_PD) ori[k] = ov[t]; }
+    } else {  // caller's level-0 image with unaligned rows: bytes
+        for (int k = lane; k < 31 * 31; k += 64) {
+            const int r = k / 31, c = k - r * 31;
+            reinterpret_cast<uint8_t*>(ori)[r * (PSL_ORI_PD * 4) + (cx - 15 - oc0) + c] = img[(size_t)(or0 + r) * pitch + cx - 15 + c];
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+
     // intensity centroid over the radius-15 disc: lanes 0..30 take column u = lane-15 for v >= 0,
     // lanes 32..62 the same column for v < 0
     int m10 = 0, m01 = 0;
@@ -632,14 +963,16 @@ __global__ __launch_bounds__(256) void k_orient_describe(OrbParams P, FrameSrc S
         const int col = lane & 31;
         if (col < 31) {
             const int u = col - 15, au = u < 0 ? -u : u;
-            const uint8_t* c = img + (size_t)cy * pitch + cx + u;
+            const uint8_t* c = reinterpret_cast<const uint8_t*>(ori) + 15 * (PSL_ORI_PD * 4) + (cx - oc0) + u;
             int colsum = 0, vsum = 0;
             if (lane < 32) {
+#pragma unroll
                 for (int v = 0; v <= 15; ++v)
-                    if (au <= P.umax[v]) { const int val = c[(ptrdiff_t)v * pitch]; colsum += val; vsum += v * val; }
+                    if (au <= P.umax[v]) { const int val = c[v * (PSL_ORI_PD * 4)]; colsum += val; vsum += v * val; }
             } else {
+#pragma unroll
                 for (int v = 1; v <= 15; ++v)
-                    if (au <= P.umax[v]) { const int val = c[-(ptrdiff_t)v * pitch]; colsum += val; vsum -= v * val; }
+                    if (au <= P.umax[v]) { const int val = c[-v * (PSL_ORI_PD * 4)]; colsum += val; vsum -= v * val; }
             }
             m10 = u * colsum;
             m01 = vsum;
@@ -653,7 +986,7 @@ __global__ __launch_bounds__(256) void k_orient_describe(OrbParams P, FrameSrc S
     const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
     float a, b;
     psl_sincosf(PSL_FMUL(angle, factorPI), &b, &a);  // a = cos, b = sin
-    const uint8_t* bl = blur + (size_t)frame * blur_fstride + L.blur_off + (size_t)cy * L.pitch + cx;
+    const uint8_t* pb = reinterpret_cast<const uint8_t*>(patch) + 18 * (PSL_DESC_PD * 4) + (cx - pc0);
     uint32_t nib = 0;
 #pragma unroll
     for (int cmp = 0; cmp < 4; ++cmp) {
@@ -663,7 +996,7 @@ __global__ __launch_bounds__(256) void k_orient_describe(OrbParams P, FrameSrc S
         const int c0 = psl_cvround_f(PSL_FSUB(PSL_FMUL(x0, a), PSL_FMUL(y0, b)));
         const int r1 = psl_cvround_f(PSL_FADD(PSL_FMUL(x1, b), PSL_FMUL(y1, a)));
         const int c1 = psl_cvround_f(PSL_FSUB(PSL_FMUL(x1, a), PSL_FMUL(y1, b)));
-        const int t0 = bl[(ptrdiff_t)r0 * L.pitch + c0], t1 = bl[(ptrdiff_t)r1 * L.pitch + c1];
+        const int t0 = pb[r0 * (PSL_DESC_PD * 4) + c0], t1 = pb[r1 * (PSL_DESC_PD * 4) + c1];
         nib |= (uint32_t)(t0 < t1) << cmp;
     }
     uint32_t v = nib << ((lane & 1) * 4);           // byte lane/2

@@ -11,6 +11,7 @@
 // exactly with a fixpoint: every query picks its best candidate among those not taken by an
 // EARLIER query; "taken by" is recomputed from the current picks until nothing changes.  By
 // induction over the query index the fixpoint is the sequential result.
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -226,8 +227,8 @@ struct MatchArgs {
     int* match;
     int* assigned;
     int* nmatches;
-    uint32_t* topk;   // [pair][qstride][4]: the 4 smallest keys (dist << 16 | CSR position) of every query
-    uint8_t* more;    // [pair][qstride]: the query has more than 4 gated candidates
+    uint32_t* topk;   // [pair][qstride][PSL_TOPK]: the smallest keys (dist << 16 | CSR position) of every query, ascending
+    uint8_t* more;    // [pair][qstride]: the query has more than PSL_TOPK gated candidates
 };
 
 #define PSL_KEY_INF 0xffffffffu
@@ -263,12 +264,17 @@ __device__ __forceinline__ FrameView psl_frame_view(const FrameStore& S, int slo
     return V;
 }
 
-// One wave scans the GetFeaturesInArea window of one query (src/Frame.cc:985-1038): lane l walks grid
-// column nMinCellX + l, whose cells nMinCellY..nMaxCellY are one contiguous CSR run.  Returns (in every
-// lane) the 4 smallest keys among the candidates that pass the level / window / stereo gates and are
-// neither taken initially nor (blocker != NULL) taken by an earlier query; *ncand = their number.
-__device__ void psl_window_scan(const FrameView& V, const PslProjQuery& q, const uint32_t* qd, const uint8_t* taken, const int* blocker,
-                                int qi, uint32_t (&t)[4], int* ncand) {
+// GetFeaturesInArea window of one query (src/Frame.cc:985-1038), one wave per query.  Grid column ix of the window
+// (cells nMinCellY..nMaxCellY) is one contiguous CSR run; lane l fetches the run of column nMinCellX + l and a wave
+// scan flattens the runs into candidate numbers 0..T-1 in the reference's visiting order.  Lane l then evaluates
+// candidates l, l + 64, ...: every candidate costs the same three dependent fetches (run bounds -> keypoint index
+// -> keypoint, descriptor, gates) no matter how many share its column, and all lanes work even for narrow windows.
+struct WindowCols {
+    int start, excl, incl, T;
+    bool checkLevels;
+};
+
+__device__ __forceinline__ WindowCols psl_window_cols(const FrameView& V, const PslProjQuery& q) {
     const int lane = threadIdx.x & 63;
     const FrameMeta& M = V.M;
     const float r = q.radius;
@@ -276,40 +282,80 @@ __device__ void psl_window_scan(const FrameView& V, const PslProjQuery& q, const
     const int maxCX = min(PSL_GRID_COLS - 1, (int)__builtin_ceilf(PSL_FMUL(PSL_FADD(PSL_FSUB(q.u, M.minX), r), M.invW)));
     const int minCY = max(0, (int)__builtin_floorf(PSL_FMUL(PSL_FSUB(PSL_FSUB(q.v, M.minY), r), M.invH)));
     const int maxCY = min(PSL_GRID_ROWS - 1, (int)__builtin_ceilf(PSL_FMUL(PSL_FADD(PSL_FSUB(q.v, M.minY), r), M.invH)));
-    t[0] = t[1] = t[2] = t[3] = PSL_KEY_INF;
-    int cnt = 0;
     const bool window = minCX < PSL_GRID_COLS && maxCX >= 0 && minCY < PSL_GRID_ROWS && maxCY >= 0;
-    const int ix = minCX + lane;
-    if (window && ix <= maxCX) {
-        const bool checkLevels = (q.min_level > 0) || (q.max_level >= 0);
-        const int p1 = V.gstart[ix * PSL_GRID_ROWS + maxCY + 1];
-        for (int p = V.gstart[ix * PSL_GRID_ROWS + minCY]; p < p1; ++p) {
-            const int i2 = V.gidx[p];
-            const PslKeyPoint kp = V.kps[i2];
-            if (checkLevels) {
-                if (kp.octave < q.min_level) continue;
-                if (q.max_level >= 0 && kp.octave > q.max_level) continue;
-            }
-            if (!(__builtin_fabsf(PSL_FSUB(kp.x, q.u)) < r && __builtin_fabsf(PSL_FSUB(kp.y, q.v)) < r)) continue;
-            if (i2 >= V.n) continue;
-            if (taken && taken[i2]) continue;                 // already holds a map point with observations (:1401-1403)
-            if (blocker && blocker[i2] < qi) continue;        // taken by an earlier query of this call
-            const float ur = V.uright[i2];
-            if (ur > 0 && __builtin_fabsf(PSL_FSUB(q.ur, ur)) > r) continue;  // (:1405-1411)
-            psl_top4_insert(t, ((uint32_t)psl_hamming256(qd, V.desc + (size_t)i2 * 8) << 16) | (uint32_t)p);
-            ++cnt;
-        }
+    WindowCols W;
+    W.start = 0;
+    int len = 0;
+    if (window && minCX + lane <= maxCX) {
+        const int ix = minCX + lane;
+        W.start = V.gstart[ix * PSL_GRID_ROWS + minCY];
+        len = V.gstart[ix * PSL_GRID_ROWS + maxCY + 1] - W.start;
     }
+    int incl = len;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const uint32_t a0 = __shfl_xor(t[0], o), a1 = __shfl_xor(t[1], o), a2 = __shfl_xor(t[2], o), a3 = __shfl_xor(t[3], o);
-        psl_top4_insert(t, a0); psl_top4_insert(t, a1); psl_top4_insert(t, a2); psl_top4_insert(t, a3);
-        cnt += __shfl_xor(cnt, o);
-    }
-    *ncand = cnt;
+    for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(incl, o); if (lane >= o) incl += u; }
+    W.incl = incl;
+    W.excl = incl - len;
+    W.T = __shfl(incl, 63);
+    W.checkLevels = (q.min_level > 0) || (q.max_level >= 0);
+    return W;
 }
 
-// Pass 1 (wide): every query of every pair in parallel, one wave each; ignores first-come blocking.
+// Key (distance << 16 | CSR position) of candidate number j, PSL_KEY_INF if j >= T or a gate rejects it: level band,
+// window, stereo (:1405-1411), taken initially (:1401-1403), taken by an earlier query of this call (blocker != NULL).
+// Called by all 64 lanes (shuffles inside).
+__device__ __forceinline__ uint32_t psl_window_key(const FrameView& V, const PslProjQuery& q, const uint32_t* qd, const uint8_t* taken,
+                                                   const int* blocker, int qi, const WindowCols& W, int j) {
+    int c = 0;  // number of columns whose inclusive count is <= j == the column of candidate j
+#pragma unroll
+    for (int step = 32; step > 0; step >>= 1) {
+        const int v = __shfl(W.incl, c + step - 1);
+        if (v <= j) c += step;
+    }
+    c = c < 63 ? c : 63;
+    const int cs = __shfl(W.start, c), ce = __shfl(W.excl, c);
+    uint32_t key = PSL_KEY_INF;
+    if (j < W.T) {
+        const float r = q.radius;
+        const int p = cs + (j - ce);
+        const int i2 = V.gidx[p];
+        const float2 xy = *reinterpret_cast<const float2*>(&V.kps[i2].x);
+        const int octave = V.kps[i2].octave;
+        const float ur = V.uright[i2];
+        const uint4 d0 = *reinterpret_cast<const uint4*>(V.desc + (size_t)i2 * 8);
+        const uint4 d1 = *reinterpret_cast<const uint4*>(V.desc + (size_t)i2 * 8 + 4);
+        bool ok = i2 < V.n;
+        if (W.checkLevels) ok = ok && !(octave < q.min_level) && !(q.max_level >= 0 && octave > q.max_level);
+        ok = ok && (__builtin_fabsf(PSL_FSUB(xy.x, q.u)) < r && __builtin_fabsf(PSL_FSUB(xy.y, q.v)) < r);
+        if (taken) ok = ok && !taken[i2];
+        if (blocker) ok = ok && !(blocker[i2] < qi);
+        ok = ok && !(ur > 0 && __builtin_fabsf(PSL_FSUB(q.ur, ur)) > r);
+        const int dist = __popc(qd[0] ^ d0.x) + __popc(qd[1] ^ d0.y) + __popc(qd[2] ^ d0.z) + __popc(qd[3] ^ d0.w) +
+                         __popc(qd[4] ^ d1.x) + __popc(qd[5] ^ d1.y) + __popc(qd[6] ^ d1.z) + __popc(qd[7] ^ d1.w);
+        if (ok) key = ((uint32_t)dist << 16) | (uint32_t)p;
+    }
+    return key;
+}
+
+// Ascending bitonic sort of one 32-bit key per lane across the wave.
+__device__ __forceinline__ uint32_t psl_wave_sort(uint32_t v) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            const uint32_t o = __shfl_xor(v, j);
+            const bool up = (lane & k) == 0, lower = (lane & j) == 0;
+            v = (up == lower) ? min(v, o) : max(v, o);
+        }
+    }
+    return v;
+}
+
+#define PSL_TOPK 8   // cached best candidates per query
+
+// Pass 1 (wide): every query of every pair in parallel, one wave each; ignores first-come blocking.  Writes the
+// PSL_TOPK smallest keys of the query in ascending order and whether the window holds more gated candidates.
 __global__ __launch_bounds__(256) void k_window_eval(MatchArgs A) {
     const int pair = blockIdx.y, qi = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     int nq = A.nq_arr ? A.nq_arr[pair] : A.nq_single;
@@ -321,29 +367,42 @@ __global__ __launch_bounds__(256) void k_window_eval(MatchArgs A) {
     uint32_t qd[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) qd[k] = QD[k];
-    uint32_t t[4];
-    int cnt;
-    psl_window_scan(V, q, qd, A.taken ? A.taken + (size_t)pair * A.S.cap : nullptr, nullptr, qi, t, &cnt);
-    if (lane == 0) {
-        uint32_t* o = A.topk + ((size_t)pair * A.qstride + qi) * 4;
-        o[0] = t[0]; o[1] = t[1]; o[2] = t[2]; o[3] = t[3];
-        A.more[(size_t)pair * A.qstride + qi] = cnt > 4;
+    const uint8_t* taken = A.taken ? A.taken + (size_t)pair * A.S.cap : nullptr;
+    const WindowCols W = psl_window_cols(V, q);
+    uint32_t best = PSL_KEY_INF;  // lanes 0..PSL_TOPK-1: running smallest keys, ascending
+    int cnt = 0;
+    for (int base = 0; base < W.T; base += 64) {
+        uint32_t key = psl_window_key(V, q, qd, taken, nullptr, qi, W, base + lane);
+        cnt += __popcll(__ballot(key != PSL_KEY_INF));
+        key = psl_wave_sort(key);
+        if (base > 0) {  // merge this round's smallest with the running ones
+            const uint32_t o = __shfl(key, (lane - PSL_TOPK) & 63);
+            key = psl_wave_sort(lane < PSL_TOPK ? best : (lane < 2 * PSL_TOPK ? o : PSL_KEY_INF));
+        }
+        best = key;
     }
+    if (lane < PSL_TOPK) A.topk[((size_t)pair * A.qstride + qi) * PSL_TOPK + lane] = best;
+    if (lane == 0) A.more[(size_t)pair * A.qstride + qi] = cnt > PSL_TOPK;
 }
 
 // Pass 2: one workgroup per frame resolves the sequential semantics by a fixpoint on "taken by an earlier
-// query" using the cached top-4 lists (thread per query); a query whose whole list is blocked while it has
-// more candidates is re-scanned in full by a wave (rare).  Then the rotation histogram and the outputs.
+// query".  A thread owns QM/BS queries and keeps their cached candidate lists (key, keypoint, octave) in
+// registers, so an iteration touches only LDS: phase A picks every query's best candidate not taken by an
+// earlier query (blockers of the previous iteration), phase B rebuilds the blockers from the picks.  A query
+// whose whole list is blocked while its window holds more candidates is re-scanned in full by a wave (rare).
+// Then the rotation histogram and the outputs.
 // MODE 0: SearchByProjection(cur,last) (:1328-1470); MODE 1: SearchByProjection(F, MapPoints) (:45-129).
 template <int MODE, int QM, int BS>
 __global__ __launch_bounds__(BS) void k_window_resolve(MatchArgs A) {
+    constexpr int R = QM / BS;
     __shared__ int s_choice[QM];
-    __shared__ int s_blocker[QM];
+    __shared__ int s_blk[2][QM];
     __shared__ uint8_t s_bin[QM];
     __shared__ uint8_t s_slow[QM];
     __shared__ int s_hist[PSL_HISTO];
     __shared__ int s_ind[3];
-    __shared__ int s_flag[3];  // 0: changed, 1: nmatches, 2: any slow
+    __shared__ int s_changed[3], s_anyslow[3], s_nm;
+    int* s_blocker = s_blk[0];
 
     const int pair = blockIdx.x, slot = A.slot0 + pair, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const FrameStore& S = A.S;
@@ -354,80 +413,137 @@ __global__ __launch_bounds__(BS) void k_window_resolve(MatchArgs A) {
     const PslProjQuery* Q = A.q + (size_t)pair * A.qstride;
     const uint32_t* QD = reinterpret_cast<const uint32_t*>(A.qdesc + (size_t)pair * A.qstride * 32);
     const uint8_t* taken = A.taken ? A.taken + (size_t)pair * S.cap : nullptr;
-    const uint32_t* TK = A.topk + (size_t)pair * A.qstride * 4;
+    const uint32_t* TK = A.topk + (size_t)pair * A.qstride * PSL_TOPK;
     const uint8_t* MORE = A.more + (size_t)pair * A.qstride;
 
+    // candidate lists of this thread's queries: keys (distance << 16 | CSR position, ascending, INF-terminated) and
+    // per candidate keypoint index | octave << 12
+    uint32_t K[R][PSL_TOPK];
+    uint32_t CP[R][PSL_TOPK / 2];  // two 16-bit entries per register
+    uint32_t flags = 0;  // bit r: query blocks, bit 8 + r: window holds more candidates than the list
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int qi = tid + r * BS;
+        if (qi < nq) {
+            const uint4 k0 = *reinterpret_cast<const uint4*>(TK + (size_t)qi * PSL_TOPK);
+            const uint4 k1 = *reinterpret_cast<const uint4*>(TK + (size_t)qi * PSL_TOPK + 4);
+            K[r][0] = k0.x; K[r][1] = k0.y; K[r][2] = k0.z; K[r][3] = k0.w; K[r][4] = k1.x; K[r][5] = k1.y; K[r][6] = k1.z; K[r][7] = k1.w;
+            flags |= (Q[qi].blocks ? 1u : 0u) << r;
+            flags |= (MORE[qi] ? 1u : 0u) << (8 + r);
+        } else {
+#pragma unroll
+            for (int e = 0; e < PSL_TOPK; ++e) K[r][e] = PSL_KEY_INF;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int h = 0; h < PSL_TOPK / 2; ++h) {
+            uint32_t c0 = 0, c1 = 0;
+            if (K[r][2 * h] != PSL_KEY_INF) { c0 = (uint32_t)V.gidx[K[r][2 * h] & 0xffff]; if (MODE == 1) c0 |= (uint32_t)V.kps[c0].octave << 12; }
+            if (K[r][2 * h + 1] != PSL_KEY_INF) { c1 = (uint32_t)V.gidx[K[r][2 * h + 1] & 0xffff]; if (MODE == 1) c1 |= (uint32_t)V.kps[c1].octave << 12; }
+            CP[r][h] = c0 | (c1 << 16);
+        }
+#define PSL_CI(r, e) ((CP[r][(e) >> 1] >> (16 * ((e) & 1))) & 0xffffu)
+
     for (int i = tid; i < nq; i += BS) s_choice[i] = -2;
-    for (int i = tid; i < n; i += BS) s_blocker[i] = 0x7fffffff;
+    for (int i = tid; i < n; i += BS) s_blk[0][i] = 0x7fffffff;
+    if (tid < 3) { s_changed[tid] = 0; s_anyslow[tid] = 0; }
     __syncthreads();
 
-    // decide a query from its two best non-blocked keys
-    auto decide = [&](uint32_t k1, uint32_t k2) -> int {
+    // decide a query from its two best non-blocked candidates (key, keypoint | octave << 12)
+    auto decide = [&](uint32_t k1, uint32_t c1, uint32_t k2, uint32_t c2) -> int {
         if (k1 == PSL_KEY_INF) return -1;
-        const int bestDist = (int)(k1 >> 16), bestIdx = V.gidx[k1 & 0xffff];
+        const int bestDist = (int)(k1 >> 16);
         bool ok = bestDist <= PSL_TH_HIGH;
         if (MODE == 1 && ok && k2 != PSL_KEY_INF) {
             const int bestDist2 = (int)(k2 >> 16);
-            const int l1 = V.kps[bestIdx].octave, l2 = V.kps[V.gidx[k2 & 0xffff]].octave;
-            if (l1 == l2 && (float)bestDist > PSL_FMUL(A.nnratio, (float)bestDist2)) ok = false;  // (:118-121)
+            if ((c1 >> 12) == (c2 >> 12) && (float)bestDist > PSL_FMUL(A.nnratio, (float)bestDist2)) ok = false;  // (:118-121)
         }
-        return ok ? bestIdx : -1;
+        return ok ? (int)(c1 & 0xfff) : -1;
     };
 
+    int cur = 0;
     for (int iter = 0; iter <= nq; ++iter) {
-        if (tid == 0) { s_flag[0] = 0; s_flag[2] = 0; }
-        __syncthreads();
-        for (int qi = tid; qi < nq; qi += BS) {  // fast path: cached lists
-            uint32_t k1 = PSL_KEY_INF, k2 = PSL_KEY_INF;
-            int found = 0;
-            bool exhausted = true;  // true if the list ended before we had what we need
-            for (int r = 0; r < 4; ++r) {
-                const uint32_t key = TK[(size_t)qi * 4 + r];
-                if (key == PSL_KEY_INF) break;
-                const int c = V.gidx[key & 0xffff];
-                if (s_blocker[c] < qi) continue;
-                if (found == 0) { k1 = key; found = 1; if (MODE == 0) { exhausted = false; break; } }
-                else { k2 = key; found = 2; exhausted = false; break; }
-            }
-            const bool slow = exhausted && MORE[qi];  // the list ran out but the window holds more candidates
-            s_slow[qi] = slow;
-            if (slow) s_flag[2] = 1;
-            else {
-                const int pick = decide(k1, k2);
-                if (s_choice[qi] != pick) { s_choice[qi] = pick; s_flag[0] = 1; }
+        const int f = iter % 3;
+        const int* blk = s_blk[cur];
+        // phase A: picks from the cached lists
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int qi = tid + r * BS;
+            if (qi < nq) {
+                uint32_t k1 = PSL_KEY_INF, k2 = PSL_KEY_INF, c1 = 0, c2 = 0;
+                int found = 0;
+                bool exhausted = true;  // the list ended before we had what we need
+#pragma unroll
+                for (int e = 0; e < PSL_TOPK; ++e) {
+                    const uint32_t key = K[r][e];
+                    const bool live = !(found == (MODE == 0 ? 1 : 2)) && key != PSL_KEY_INF;
+                    const uint32_t ci = PSL_CI(r, e);
+                    if (live && !(blk[ci & 0xfff] < qi)) {
+                        if (found == 0) { k1 = key; c1 = ci; found = 1; }
+                        else { k2 = key; c2 = ci; found = 2; }
+                    }
+                }
+                exhausted = found < (MODE == 0 ? 1 : 2);
+                const bool slow = exhausted && ((flags >> (8 + r)) & 1);  // the list ran out but the window holds more
+                s_slow[qi] = slow;
+                if (slow) s_anyslow[f] = 1;
+                else {
+                    const int pick = decide(k1, c1, k2, c2);
+                    if (s_choice[qi] != pick) { s_choice[qi] = pick; s_changed[f] = 1; }
+                }
             }
         }
+        for (int i = tid; i < n; i += BS) s_blk[cur ^ 1][i] = 0x7fffffff;
+        if (tid == 0) { s_changed[(iter + 1) % 3] = 0; s_anyslow[(iter + 1) % 3] = 0; }
         __syncthreads();
-        if (s_flag[2]) {  // slow path: full window scan with the current blockers, one wave per query
+        if (s_anyslow[f]) {  // slow path: full window scan with the current blockers, one wave per query
             for (int qi = wave; qi < nq; qi += BS / 64) {
                 if (!s_slow[qi]) continue;
                 const PslProjQuery q = Q[qi];
                 uint32_t qd[8];
 #pragma unroll
                 for (int k = 0; k < 8; ++k) qd[k] = QD[(size_t)qi * 8 + k];
-                uint32_t t[4];
-                int cnt;
-                psl_window_scan(V, q, qd, taken, s_blocker, qi, t, &cnt);
-                const int pick = decide(t[0], t[1]);
-                if (lane == 0 && s_choice[qi] != pick) { s_choice[qi] = pick; s_flag[0] = 1; }
+                const WindowCols W = psl_window_cols(V, q);
+                uint32_t t0 = PSL_KEY_INF, t1 = PSL_KEY_INF;  // two smallest keys
+                for (int base = 0; base < W.T; base += 64) {
+                    const uint32_t key = psl_window_key(V, q, qd, taken, blk, qi, W, base + lane);
+                    if (key < t0) { t1 = t0; t0 = key; } else if (key < t1) t1 = key;
+                }
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) {
+                    const uint32_t a0 = __shfl_xor(t0, o), a1 = __shfl_xor(t1, o);
+                    const uint32_t lo = min(t0, a0), hi = max(t0, a0);
+                    t1 = min(hi, min(t1, a1));
+                    t0 = lo;
+                }
+                uint32_t c1 = 0, c2 = 0;
+                if (t0 != PSL_KEY_INF) { c1 = V.gidx[t0 & 0xffff]; if (MODE == 1) c1 |= (uint32_t)V.kps[c1].octave << 12; }
+                if (t1 != PSL_KEY_INF) { c2 = V.gidx[t1 & 0xffff]; if (MODE == 1) c2 |= (uint32_t)V.kps[c2].octave << 12; }
+                const int pick = decide(t0, c1, t1, c2);
+                if (lane == 0 && s_choice[qi] != pick) { s_choice[qi] = pick; s_changed[f] = 1; }
+            }
+            __syncthreads();
+        }
+        if (!s_changed[f]) break;
+        // phase B: blockers of the next iteration
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int qi = tid + r * BS;
+            if (qi < nq && ((flags >> r) & 1)) {
+                const int c = s_choice[qi];
+                if (c >= 0) atomicMin(&s_blk[cur ^ 1][c], qi);
             }
         }
         __syncthreads();
-        const int changed = s_flag[0];
-        __syncthreads();
-        if (!changed) break;
-        for (int i = tid; i < n; i += BS) s_blocker[i] = 0x7fffffff;
-        __syncthreads();
-        for (int qi = tid; qi < nq; qi += BS) {
-            const int c = s_choice[qi];
-            if (c >= 0 && Q[qi].blocks) atomicMin(&s_blocker[c], qi);
-        }
-        __syncthreads();
+        cur ^= 1;
     }
+    __syncthreads();
 
     // rotation consistency (:1431-1467)
     if (tid < PSL_HISTO) s_hist[tid] = 0;
-    if (tid == 0) { s_ind[0] = s_ind[1] = s_ind[2] = -1; s_flag[1] = 0; }
+    if (tid == 0) { s_ind[0] = s_ind[1] = s_ind[2] = -1; s_nm = 0; }
     __syncthreads();
     const bool ori = MODE == 0 && A.check_ori;
     if (ori) {
@@ -481,13 +597,13 @@ __global__ __launch_bounds__(BS) void k_window_resolve(MatchArgs A) {
         }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) local += __shfl_xor(local, o);
-    if (lane == 0 && local) atomicAdd(&s_flag[1], local);
+    if (lane == 0 && local) atomicAdd(&s_nm, local);
     __syncthreads();
     if (A.assigned) {
         int* asg = A.assigned + (size_t)pair * S.cap;
         for (int i = tid; i < V.M.n; i += BS) asg[i] = i < n ? s_blocker[i] : -1;
     }
-    if (tid == 0) A.nmatches[pair] = s_flag[1];
+    if (tid == 0) A.nmatches[pair] = s_nm;
 }
 
 // BFMatcher(NORM_HAMMING).knnMatch(k = 2): one wave per query row, lanes stride the train rows.
@@ -527,9 +643,9 @@ struct pslfe_frame {
     int* d_match = nullptr;
     int* d_assigned = nullptr;
     int* d_nm = nullptr;
-    uint32_t* d_topk = nullptr;  // [max_frames][cap][4]
+    uint32_t* d_topk = nullptr;  // [max_frames][cap][PSL_TOPK]
     uint8_t* d_more = nullptr;   // [max_frames][cap]
-    uint32_t* d_topk1 = nullptr; // [PSL_QMAX][4] for the host-pointer entry points
+    uint32_t* d_topk1 = nullptr; // [PSL_QMAX][PSL_TOPK] for the host-pointer entry points
     uint8_t* d_more1 = nullptr;
     float* d_depth = nullptr;    // [max_frames][cap] mvDepth (RGB-D post-processing)
     float* d_bounds = nullptr;   // [4] scratch for k_image_bounds
@@ -565,9 +681,8 @@ int host_search(pslfe_frame* f, int slot, const PslProjQuery* queries, const uin
     {
         PSL_STAGE_BEGIN(f->ctx, "match.window");
         k_window_eval<<<dim3((nq + 3) / 4, 1), 256, 0, st>>>(A);
-        const bool small = nq <= 2048 && f->cap <= 2048;
-        if (mode == 0) { if (small) k_window_resolve<0, 2048, 256><<<1, 256, 0, st>>>(A); else k_window_resolve<0, PSL_QMAX, 1024><<<1, 1024, 0, st>>>(A); }
-        else { if (small) k_window_resolve<1, 2048, 256><<<1, 256, 0, st>>>(A); else k_window_resolve<1, PSL_QMAX, 1024><<<1, 1024, 0, st>>>(A); }
+        if (mode == 0) k_window_resolve<0, PSL_QMAX, 1024><<<1, 1024, 0, st>>>(A);
+        else k_window_resolve<1, PSL_QMAX, 1024><<<1, 1024, 0, st>>>(A);
         PSL_STAGE_END(f->ctx, "match.window");
     }
     PSL_HIP(hipGetLastError());
@@ -607,9 +722,9 @@ int pslfe_frame_create(pslfe_ctx* ctx, int max_keypoints, int max_frames, pslfe_
     A((void**)&f->d_match, PSL_QMAX * sizeof(int));
     A((void**)&f->d_assigned, K * sizeof(int));
     A((void**)&f->d_nm, sizeof(int));
-    A((void**)&f->d_topk, F * K * 4 * sizeof(uint32_t));
+    A((void**)&f->d_topk, F * K * PSL_TOPK * sizeof(uint32_t));
     A((void**)&f->d_more, F * K);
-    A((void**)&f->d_topk1, (size_t)PSL_QMAX * 4 * sizeof(uint32_t));
+    A((void**)&f->d_topk1, (size_t)PSL_QMAX * PSL_TOPK * sizeof(uint32_t));
     A((void**)&f->d_more1, PSL_QMAX);
     A((void**)&f->d_depth, F * K * sizeof(float));
     A((void**)&f->d_bounds, 4 * sizeof(float));
@@ -821,10 +936,8 @@ int pslfe_orb_search_by_projection_last_device(pslfe_frame* cur, int slot0, int 
     {
         PSL_STAGE_BEGIN(cur->ctx, "match.window");
         k_window_eval<<<dim3((std::min(qstride, PSL_QMAX) + 3) / 4, npairs), 256, 0, cur->ctx->stream>>>(A);
-        // few frames: one big workgroup per frame finishes its frame sooner; many frames: small workgroups so
-        // that 8 frames share a CU and overlap their barrier-separated phases
-        if (qstride <= 2048 && cur->cap <= 2048 && npairs >= 4 * cur->ctx->cu_count) k_window_resolve<0, 2048, 256><<<npairs, 256, 0, cur->ctx->stream>>>(A);
-        else k_window_resolve<0, PSL_QMAX, 1024><<<npairs, 1024, 0, cur->ctx->stream>>>(A);
+        // one 1024-thread workgroup per frame: measured faster than 512-thread workgroups at 256 and at 4096 frames
+        k_window_resolve<0, PSL_QMAX, 1024><<<npairs, 1024, 0, cur->ctx->stream>>>(A);
         PSL_STAGE_END(cur->ctx, "match.window");
     }
     PSL_HIP(hipGetLastError());

@@ -1,6 +1,7 @@
 // libpslfe: ORB extractor object (== ORB_SLAM2::ORBextractor) over the HIP kernels. Product code.
 // Reference: src/ORBextractor.cc, include/ORBextractor.h.
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -94,6 +95,8 @@ struct pslfe_orb {
     uint8_t* d_in = nullptr;  // staging for the host-buffer entry points
     size_t in_fstride = 0;
     int in_pitch = 0;
+    bool fast_v1 = getenv("PSLFE_FAST_V1") != nullptr;        // A/B switch for the one-pixel-per-thread FAST kernel
+    bool pyr_simple = getenv("PSLFE_PYR_SIMPLE") != nullptr;  // A/B switch for the untiled pyramid kernel
 
     int last_nframes = 0;
     FrameSrc last_src = {};
@@ -233,14 +236,20 @@ struct pslfe_orb {
         {
             PSL_STAGE_BEGIN(ctx, "orb.pyramid");
             for (int l = 1; l < nlevels; ++l) {
-                dim3 grid((P.lv[l].pitch / 4 + 63) / 64, (P.lv[l].h + 3) / 4, F);
-                k_pyr_resize<<<grid, 256, 0, st>>>(P, S, l, d_xofs[l], d_alpha[l], d_yofs[l], d_beta[l]);
+                if (pyr_simple) {
+                    dim3 grid((P.lv[l].pitch / 4 + 63) / 64, (P.lv[l].h + 3) / 4, F);
+                    k_pyr_resize<<<grid, 256, 0, st>>>(P, S, l, d_xofs[l], d_alpha[l], d_yofs[l], d_beta[l]);
+                } else {
+                    dim3 grid((P.lv[l].pitch + 63) / 64, (P.lv[l].h + 15) / 16, F);
+                    k_pyr_resize_tiled<<<grid, 256, 0, st>>>(P, S, l, d_xofs[l], d_alpha[l], d_yofs[l], d_beta[l]);
+                }
             }
             PSL_STAGE_END(ctx, "orb.pyramid");
         }
         {
             PSL_STAGE_BEGIN(ctx, "orb.fast");
-            k_fast_cells<<<dim3(P.ncells, F), 256, 0, st>>>(P, S, d_cellcnt, d_cellcand);
+            if (fast_v1) k_fast_cells<<<dim3(P.ncells, F), 256, 0, st>>>(P, S, d_cellcnt, d_cellcand);
+            else k_fast_cells4<<<dim3(P.ncells, F), 256, 0, st>>>(P, S, d_cellcnt, d_cellcand);
             PSL_STAGE_END(ctx, "orb.fast");
         }
         {
