@@ -98,45 +98,26 @@ __global__ __launch_bounds__(256) void k_pyr_resize(OrbParams P, FrameSrc S, int
     *reinterpret_cast<uint32_t*>(dst + x4) = packed;
 }
 
-// Same arithmetic, source staged through LDS: a workgroup produces a 64 x 16 block of the level and first
+// Same arithmetic, source staged through LDS: a workgroup produces a 64 x 32 block of the level and first
 // copies the source rectangle it needs (<= PSL_PYR_TR rows of <= PSL_PYR_TD dwords) with coalesced dword
-// loads; the 16 taps of a thread then come from LDS instead of 16 scattered byte loads from HBM/L2.
-#define PSL_PYR_TD 40   // tile pitch in dwords (scale factors up to ~2.3)
-#define PSL_PYR_TR 40   // tile rows
+// loads; the taps of a thread then come from LDS instead of scattered byte loads from HBM/L2.  A thread makes
+// 4 adjacent pixels of two rows (16 apart), sharing the column tables; all table loads are issued before the
+// tile loads so that the workgroup pays two memory round trips, not three.
+#define PSL_PYR_TD 36   // tile pitch in dwords
+#define PSL_PYR_TR 48   // tile rows
+#define PSL_PYR_BH 32   // block height
 __global__ __launch_bounds__(256) void k_pyr_resize_tiled(OrbParams P, FrameSrc S, int level,
                                                            const int* __restrict__ xofs, const short2* __restrict__ alpha,
                                                            const int* __restrict__ yofs, const short2* __restrict__ beta) {
     __shared__ uint32_t s_tile[PSL_PYR_TR * PSL_PYR_TD];
     const OrbLevelP L = P.lv[level];
     const int frame = blockIdx.z, tid = threadIdx.x;
-    const int x0 = blockIdx.x * 64, y0 = blockIdx.y * 16;
+    const int x0 = blockIdx.x * 64, y0 = blockIdx.y * PSL_PYR_BH;
     int spitch;
     const uint8_t* src = psl_level_ptr(P, S, level - 1, frame, &spitch);
     const int sw = P.lv[level - 1].w, sh = P.lv[level - 1].h;
-    // source rectangle of this block (tables are non-decreasing)
-    const int xe = min(x0 + 63, L.w - 1), ye = min(y0 + 15, L.h - 1);
-    const int cfirst = xofs[min(x0, L.w - 1)], clast = min(xofs[xe] + 1, sw - 1);
-    const int rfirst = min(max(yofs[y0], 0), sh - 1), rlast = min(max(yofs[ye] + 1, 0), sh - 1);
-    const int cbase = cfirst & ~3;
-    const int ndw = ((clast - cbase) >> 2) + 1, nrows = rlast - rfirst + 1;
-    // dword staging needs 4-byte aligned rows whose last dword stays inside the row pitch
-    const bool staged = ndw <= PSL_PYR_TD && nrows <= PSL_PYR_TR && cfirst >= 0 &&
-                        ((reinterpret_cast<uintptr_t>(src) | (uintptr_t)spitch) & 3) == 0 && cbase + ndw * 4 <= spitch;
-    if (staged) {
-        for (int k = tid; k < nrows * ndw; k += 256) {
-            const int r = k / ndw, d = k - r * ndw;
-            s_tile[r * PSL_PYR_TD + d] = *reinterpret_cast<const uint32_t*>(src + (size_t)(rfirst + r) * spitch + cbase + d * 4);
-        }
-    }
-    __syncthreads();
-    const int dy = y0 + (tid >> 4);
+    // this thread's tables
     const int x4 = x0 + (tid & 15) * 4;
-    if (dy >= L.h || x4 >= L.pitch) return;
-    uint8_t* dst = S.pyr + (size_t)frame * S.pyr_fstride + L.img_off + (size_t)dy * L.pitch;
-    int sy0 = yofs[dy], sy1 = sy0 + 1;
-    sy0 = sy0 < 0 ? 0 : (sy0 >= sh ? sh - 1 : sy0);
-    sy1 = sy1 < 0 ? 0 : (sy1 >= sh ? sh - 1 : sy1);
-    const short2 b = beta[dy];
     int sx[4];
     short2 a[4];
 #pragma unroll
@@ -146,41 +127,75 @@ __global__ __launch_bounds__(256) void k_pyr_resize_tiled(OrbParams P, FrameSrc 
         sx[j] = xofs[dx];
         a[j] = alpha[dx];
     }
-    uint32_t packed = 0;
+    int sy0[2], sy1[2];
+    short2 b[2];
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+        const int dy = min(y0 + (tid >> 4) + 16 * rr, L.h - 1);
+        const int t = yofs[dy];
+        sy0[rr] = t < 0 ? 0 : (t >= sh ? sh - 1 : t);
+        sy1[rr] = t + 1 < 0 ? 0 : (t + 1 >= sh ? sh - 1 : t + 1);
+        b[rr] = beta[dy];
+    }
+    // source rectangle of this block (tables are non-decreasing)
+    const int xe = min(x0 + 63, L.w - 1), ye = min(y0 + PSL_PYR_BH - 1, L.h - 1);
+    const int cfirst = xofs[min(x0, L.w - 1)], clast = min(xofs[xe] + 1, sw - 1);
+    const int rfirst = min(max(yofs[y0], 0), sh - 1), rlast = min(max(yofs[ye] + 1, 0), sh - 1);
+    const int cbase = cfirst & ~3;
+    const int ndw = ((clast - cbase) >> 2) + 1, nrows = rlast - rfirst + 1;
+    // dword staging needs 4-byte aligned rows whose last dword stays inside the row pitch
+    const bool staged = ndw <= PSL_PYR_TD && nrows <= PSL_PYR_TR && cfirst >= 0 &&
+                        ((reinterpret_cast<uintptr_t>(src) | (uintptr_t)spitch) & 3) == 0 && cbase + ndw * 4 <= spitch;
     if (staged) {
-        const uint8_t* t0 = reinterpret_cast<const uint8_t*>(s_tile) + (sy0 - rfirst) * (PSL_PYR_TD * 4) - cbase;
-        const uint8_t* t1 = reinterpret_cast<const uint8_t*>(s_tile) + (sy1 - rfirst) * (PSL_PYR_TD * 4) - cbase;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            int h0, h1;
-            if (sx[j] + 1 < sw) {
-                h0 = t0[sx[j]] * a[j].x + t0[sx[j] + 1] * a[j].y;
-                h1 = t1[sx[j]] * a[j].x + t1[sx[j] + 1] * a[j].y;
-            } else {
-                h0 = t0[sx[j]] * 2048;
-                h1 = t1[sx[j]] * 2048;
-            }
-            const int v = ((((int)b.x * (h0 >> 4)) >> 16) + (((int)b.y * (h1 >> 4)) >> 16) + 2) >> 2;
-            packed |= (uint32_t)(v & 0xff) << (8 * j);
-        }
-    } else {
-        const uint8_t* r0 = src + (size_t)sy0 * spitch;
-        const uint8_t* r1 = src + (size_t)sy1 * spitch;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            int h0, h1;
-            if (sx[j] + 1 < sw) {
-                h0 = r0[sx[j]] * a[j].x + r0[sx[j] + 1] * a[j].y;
-                h1 = r1[sx[j]] * a[j].x + r1[sx[j] + 1] * a[j].y;
-            } else {
-                h0 = r0[sx[j]] * 2048;
-                h1 = r1[sx[j]] * 2048;
-            }
-            const int v = ((((int)b.x * (h0 >> 4)) >> 16) + (((int)b.y * (h1 >> 4)) >> 16) + 2) >> 2;
-            packed |= (uint32_t)(v & 0xff) << (8 * j);
+        const uint32_t mdw = (1048576u + (uint32_t)ndw - 1u) / (uint32_t)ndw;  // k / ndw == (k * mdw) >> 20 for k < 4096
+        for (int k = tid; k < nrows * ndw; k += 256) {
+            const int r = (int)(((uint32_t)k * mdw) >> 20), d = k - r * ndw;
+            s_tile[r * PSL_PYR_TD + d] = *reinterpret_cast<const uint32_t*>(src + (size_t)(rfirst + r) * spitch + cbase + d * 4);
         }
     }
-    *reinterpret_cast<uint32_t*>(dst + x4) = packed;
+    __syncthreads();
+    if (x4 >= L.pitch) return;
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+        const int dy = y0 + (tid >> 4) + 16 * rr;
+        if (dy >= L.h) break;
+        uint8_t* dst = S.pyr + (size_t)frame * S.pyr_fstride + L.img_off + (size_t)dy * L.pitch;
+        uint32_t packed = 0;
+        if (staged) {
+            const uint8_t* t0 = reinterpret_cast<const uint8_t*>(s_tile) + (sy0[rr] - rfirst) * (PSL_PYR_TD * 4) - cbase;
+            const uint8_t* t1 = reinterpret_cast<const uint8_t*>(s_tile) + (sy1[rr] - rfirst) * (PSL_PYR_TD * 4) - cbase;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                int h0, h1;
+                if (sx[j] + 1 < sw) {
+                    h0 = t0[sx[j]] * a[j].x + t0[sx[j] + 1] * a[j].y;
+                    h1 = t1[sx[j]] * a[j].x + t1[sx[j] + 1] * a[j].y;
+                } else {
+                    h0 = t0[sx[j]] * 2048;
+                    h1 = t1[sx[j]] * 2048;
+                }
+                const int v = ((((int)b[rr].x * (h0 >> 4)) >> 16) + (((int)b[rr].y * (h1 >> 4)) >> 16) + 2) >> 2;
+                packed |= (uint32_t)(v & 0xff) << (8 * j);
+            }
+        } else {
+            const uint8_t* r0 = src + (size_t)sy0[rr] * spitch;
+            const uint8_t* r1 = src + (size_t)sy1[rr] * spitch;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                int h0, h1;
+                if (sx[j] + 1 < sw) {
+                    h0 = r0[sx[j]] * a[j].x + r0[sx[j] + 1] * a[j].y;
+                    h1 = r1[sx[j]] * a[j].x + r1[sx[j] + 1] * a[j].y;
+                } else {
+                    h0 = r0[sx[j]] * 2048;
+                    h1 = r1[sx[j]] * 2048;
+                }
+                const int v = ((((int)b[rr].x * (h0 >> 4)) >> 16) + (((int)b[rr].y * (h1 >> 4)) >> 16) + 2) >> 2;
+                packed |= (uint32_t)(v & 0xff) << (8 * j);
+            }
+        }
+        *reinterpret_cast<uint32_t*>(dst + x4) = packed;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -358,24 +373,48 @@ __global__ __launch_bounds__(256, 8) void k_fast_cells(OrbParams P, FrameSrc S, 
     if (tid == 0) *out_cnt = total < P.cellcap ? total : P.cellcap;
 }
 
-// k_fast_cells4: same results as k_fast_cells, four horizontally adjacent pixels per thread.
+// k_fast_cells4: same results as k_fast_cells; dense work only where it is needed.
 //   * the tile is stored with interior column 0 at a dword boundary (tile byte = 1 + tile x), shifting the
 //     global dwords with v_alignbyte on the way in, so the 9 ring samples of the quick test for 4 pixels come
-//     from 11 aligned LDS dword reads (+ 6 alignbyte) instead of 36 byte reads;
-//   * index arithmetic, ballots and compaction are paid once per 4 pixels; a typical 31 x 31 cell is one pass;
-//   * the NMS pass reads one score dword per 4 pixels and stops there when it is zero (almost always).
+//     from 11 aligned LDS dword reads (+ 6 alignbyte) instead of 36 byte reads; four horizontally adjacent
+//     pixels per thread, so index arithmetic, ballots and compaction are paid once per 4 pixels and a typical
+//     31 x 31 cell is one pass;
+//   * the quick test records which polarity can reach minTh (ring brighter / ring darker); the score is then
+//     computed for that polarity only - exact after thresholding, because a polarity that fails the quick
+//     test scores below minTh - and both only for the rare pixel where both pass;
+//   * NMS and the raster-ordered output are driven by the compacted list (a few % of the pixels): survivors
+//     set a bit in a per-row mask, row prefix sums give the raster positions.
 #define PSL_FAST4_TP 76   // tile pitch (bytes): 1 + (64 + 6) + slack, multiple of 4
 #define PSL_FAST4_SP 72   // score pitch (bytes): interior x at byte 4 + x
 __device__ __forceinline__ uint32_t psl_alignbyte(uint32_t hi, uint32_t lo, uint32_t sh) { return __builtin_amdgcn_alignbyte(hi, lo, sh); }
+
+// max over the 16 arcs of 9 contiguous ring pixels of min(sgn * (v - ring)), minus 1: the cornerScore of one polarity
+__device__ __forceinline__ int psl_fast_score_pol(const uint8_t* c, const int tp, const int sgn) {
+    const int sv = sgn * (int)c[0];
+    int e[16];
+    e[0] = sv - sgn * c[3 * tp];       e[1] = sv - sgn * c[3 * tp + 1];   e[2] = sv - sgn * c[2 * tp + 2];   e[3] = sv - sgn * c[tp + 3];
+    e[4] = sv - sgn * c[3];            e[5] = sv - sgn * c[-tp + 3];      e[6] = sv - sgn * c[-2 * tp + 2];  e[7] = sv - sgn * c[-3 * tp + 1];
+    e[8] = sv - sgn * c[-3 * tp];      e[9] = sv - sgn * c[-3 * tp - 1];  e[10] = sv - sgn * c[-2 * tp - 2]; e[11] = sv - sgn * c[-tp - 3];
+    e[12] = sv - sgn * c[-3];          e[13] = sv - sgn * c[tp - 3];      e[14] = sv - sgn * c[2 * tp - 2];  e[15] = sv - sgn * c[3 * tp - 1];
+    int lo2[16], lo4[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) lo2[k] = min(e[k], e[(k + 1) & 15]);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) lo4[k] = min(lo2[k], lo2[(k + 2) & 15]);
+    int A = -256;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) A = max(A, min(min(lo4[k], lo4[(k + 4) & 15]), e[(k + 8) & 15]));
+    return A - 1;
+}
 
 __global__ __launch_bounds__(256, 8) void k_fast_cells4(OrbParams P, FrameSrc S, int* __restrict__ cellcnt,
                                                       uint32_t* __restrict__ cellcand) {
     __shared__ __attribute__((aligned(16))) uint32_t s_tile32[(PSL_MAXCELL + 6) * (PSL_FAST4_TP / 4) + 4];
     __shared__ __attribute__((aligned(16))) uint32_t s_score32[(PSL_MAXCELL + 2) * (PSL_FAST4_SP / 4)];
-    __shared__ int s_cnt[2][16];  // survivors per (pass, wave) at iniTh / minTh
-    __shared__ int s_off[2][17];
-    __shared__ uint16_t s_list[PSL_MAXCELL * PSL_MAXCELL];  // y << 6 | x of pixels that pass the quick test
-    __shared__ int s_nlist;
+    __shared__ uint32_t s_rowmask[2][PSL_MAXCELL][2];  // [iniTh | minTh][row][x >> 5]: NMS survivors
+    __shared__ int s_rowoff[PSL_MAXCELL];
+    __shared__ uint16_t s_list[PSL_MAXCELL * PSL_MAXCELL];  // y << 6 | x | polarity << 12 of pixels that pass the quick test
+    __shared__ int s_nlist, s_use, s_total;
     uint8_t* s_tile = reinterpret_cast<uint8_t*>(s_tile32);
     uint8_t* s_score = reinterpret_cast<uint8_t*>(s_score32);
 
@@ -409,8 +448,9 @@ __global__ __launch_bounds__(256, 8) void k_fast_cells4(OrbParams P, FrameSrc S,
     if (aligned4) {
         const int gx0 = (iniX - 1) & ~3;
         const uint32_t sh = (uint32_t)((iniX - 1) & 3);
+        const uint32_t mdw = (1048576u + (uint32_t)ndw - 1u) / (uint32_t)ndw;  // k / ndw == (k * mdw) >> 20 for k < 4096
         for (int k = tid; k < th * ndw; k += 256) {
-            const int y = k / ndw, d = k - y * ndw;
+            const int y = (int)(((uint32_t)k * mdw) >> 20), d = k - y * ndw;
             const uint32_t* g = reinterpret_cast<const uint32_t*>(img + (size_t)(iniY + y) * pitch + gx0) + d;
             s_tile32[y * (PSL_FAST4_TP / 4) + d] = psl_alignbyte(g[1], g[0], sh);
         }
@@ -421,7 +461,7 @@ __global__ __launch_bounds__(256, 8) void k_fast_cells4(OrbParams P, FrameSrc S,
         }
     }
     for (int k = tid; k < (ih + 2) * (PSL_FAST4_SP / 4); k += 256) s_score32[k] = 0;
-    if (tid < 32) (&s_cnt[0][0])[tid] = 0;
+    (&s_rowmask[0][0][0])[tid] = 0;  // 2 * 64 * 2 words
     if (tid == 0) s_nlist = 0;
     __syncthreads();
 
@@ -431,10 +471,12 @@ __global__ __launch_bounds__(256, 8) void k_fast_cells4(OrbParams P, FrameSrc S,
     const uint32_t magic = (1048576u + (uint32_t)ng - 1u) / (uint32_t)ng;  // idx / ng == (idx * magic) >> 20 for idx < 4096
     const int minTh = P.minTh, iniTh = P.iniTh;
     const unsigned long long lt = (1ull << lane) - 1ull;
-    // Quick reject, see k_fast_cells.
+    // Quick reject (exact necessary condition): an arc of 9 contains one pixel of every opposite pair, so a pixel
+    // with S >= minTh has, for the 4 pairs (0,8) (2,10) (4,12) (6,14), one member > v+minTh in each pair (polarity
+    // bit 0) or one member < v-minTh in each pair (polarity bit 1).
     for (int p = 0; p < npass; ++p) {
         const int idx = p * 256 + tid;
-        uint32_t m4 = 0;
+        uint32_t m4 = 0, pol = 0;  // pol: 2 bits per pixel
         int y = 0, g = 0;
         if (idx < nitems) {
             y = (int)(((uint32_t)idx * magic) >> 20);
@@ -457,8 +499,10 @@ __global__ __launch_bounds__(256, 8) void k_fast_cells4(OrbParams P, FrameSrc S,
                 const int r2 = (R2 >> sft) & 255, r10 = (R10 >> sft) & 255, r6 = (R6 >> sft) & 255, r14 = (R14 >> sft) & 255;
                 const int bmin = min(min(max(r0, r8), max(r4, r12)), min(max(r2, r10), max(r6, r14)));
                 const int dmax = max(max(min(r0, r8), min(r4, r12)), max(min(r2, r10), min(r6, r14)));
-                const bool pass = ((bmin > hi) | (dmax < lo)) & (4 * g + jj < iw);
-                m4 |= (uint32_t)pass << jj;
+                const bool inside = 4 * g + jj < iw;
+                const uint32_t pb = (uint32_t)((bmin > hi) & inside), pd = (uint32_t)((dmax < lo) & inside);
+                m4 |= (pb | pd) << jj;
+                pol |= (pb | (pd << 1)) << (2 * jj);
             }
         }
         // order inside s_list is irrelevant: one slot range per (wave, jj)
@@ -470,90 +514,68 @@ __global__ __launch_bounds__(256, 8) void k_fast_cells4(OrbParams P, FrameSrc S,
             if (lane == 0) base = atomicAdd(&s_nlist, tot);
             base = __shfl(base, 0);
             const uint32_t e = (uint32_t)(y << 6) | (uint32_t)(4 * g);
-            if (m4 & 1) s_list[base + __popcll(b0 & lt)] = (uint16_t)e;
-            if (m4 & 2) s_list[base + n0 + __popcll(b1 & lt)] = (uint16_t)(e + 1);
-            if (m4 & 4) s_list[base + n0 + n1 + __popcll(b2 & lt)] = (uint16_t)(e + 2);
-            if (m4 & 8) s_list[base + n0 + n1 + n2 + __popcll(b3 & lt)] = (uint16_t)(e + 3);
+            if (m4 & 1) s_list[base + __popcll(b0 & lt)] = (uint16_t)(e | ((pol & 3) << 12));
+            if (m4 & 2) s_list[base + n0 + __popcll(b1 & lt)] = (uint16_t)((e + 1) | (((pol >> 2) & 3) << 12));
+            if (m4 & 4) s_list[base + n0 + n1 + __popcll(b2 & lt)] = (uint16_t)((e + 2) | (((pol >> 4) & 3) << 12));
+            if (m4 & 8) s_list[base + n0 + n1 + n2 + __popcll(b3 & lt)] = (uint16_t)((e + 3) | (((pol >> 6) & 3) << 12));
         }
     }
     __syncthreads();
     const int nlist = s_nlist;
     for (int k = tid; k < nlist; k += 256) {
         const int e = s_list[k];
-        const int y = e >> 6, x = e & 63;
-        int s = psl_fast_score(&s_tile[(y + 3) * PSL_FAST4_TP + x + 4], PSL_FAST4_TP);
+        const int y = (e >> 6) & 63, x = e & 63, pl = e >> 12;
+        const uint8_t* c = &s_tile[(y + 3) * PSL_FAST4_TP + x + 4];
+        // polarity bit 0: ring brighter than the centre (ring - v), bit 1: ring darker (v - ring)
+        int s = psl_fast_score_pol(c, PSL_FAST4_TP, (pl & 1) ? -1 : 1);
+        if (pl == 3) s = max(s, psl_fast_score_pol(c, PSL_FAST4_TP, 1));
         s = s < minTh ? 0 : (s > 255 ? 255 : s);
         s_score[(y + 1) * PSL_FAST4_SP + x + 4] = (uint8_t)s;
     }
     __syncthreads();
-
-    uint32_t keep_ini = 0, keep_min = 0;  // bits 4p..4p+3: pixels of this thread's item of pass p that survive
-    for (int p = 0; p < npass; ++p) {
-        const int idx = p * 256 + tid;
-        uint32_t f_min = 0, f_ini = 0;
-        if (idx < nitems) {
-            const int y = (int)(((uint32_t)idx * magic) >> 20), g = idx - y * ng;
-            const uint32_t* r = &s_score32[(y + 1) * (PSL_FAST4_SP / 4) + g];
-            const uint32_t C = r[1];
-            if (C) {
-                const uint32_t* ru = r - (PSL_FAST4_SP / 4);
-                const uint32_t* rd = r + (PSL_FAST4_SP / 4);
-                const uint32_t u0 = ru[0], u1 = ru[1], u2 = ru[2], m0 = r[0], m2 = r[2], d0 = rd[0], d1 = rd[1], d2 = rd[2];
-                const uint32_t UL = psl_alignbyte(u1, u0, 3), UR = psl_alignbyte(u2, u1, 1);
-                const uint32_t ML = psl_alignbyte(C, m0, 3), MR = psl_alignbyte(m2, C, 1);
-                const uint32_t DL = psl_alignbyte(d1, d0, 3), DR = psl_alignbyte(d2, d1, 1);
-#pragma unroll
-                for (int jj = 0; jj < 4; ++jj) {
-                    const int sft = 8 * jj;
-                    const int s = (C >> sft) & 255;
-                    const int m = max(max(max((int)((UL >> sft) & 255), (int)((u1 >> sft) & 255)), max((int)((UR >> sft) & 255), (int)((ML >> sft) & 255))),
-                                      max(max((int)((MR >> sft) & 255), (int)((DL >> sft) & 255)), max((int)((d1 >> sft) & 255), (int)((DR >> sft) & 255))));
-                    const bool fm = s > m;  // s == 0 never passes
-                    f_min |= (uint32_t)fm << jj;
-                    f_ini |= (uint32_t)(fm && s >= iniTh) << jj;
-                }
+    // cv::FAST's NMS: strictly greater than the 8 neighbours (scores outside the interior are 0)
+    for (int k = tid; k < nlist; k += 256) {
+        const int e = s_list[k];
+        const int y = (e >> 6) & 63, x = e & 63;
+        const uint8_t* c = &s_score[(y + 1) * PSL_FAST4_SP + x + 4];
+        const int s = c[0];
+        if (s > 0) {
+            const int m = max(max(max((int)c[-1], (int)c[1]), max((int)c[-PSL_FAST4_SP - 1], (int)c[-PSL_FAST4_SP])),
+                              max(max((int)c[-PSL_FAST4_SP + 1], (int)c[PSL_FAST4_SP - 1]), max((int)c[PSL_FAST4_SP], (int)c[PSL_FAST4_SP + 1])));
+            if (s > m) {
+                atomicOr(&s_rowmask[1][y][x >> 5], 1u << (x & 31));
+                if (s >= iniTh) atomicOr(&s_rowmask[0][y][x >> 5], 1u << (x & 31));
             }
         }
-        int c_ini = __popc(f_ini), c_min = __popc(f_min);
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { c_ini += __shfl_xor(c_ini, o); c_min += __shfl_xor(c_min, o); }
-        if (lane == 0) { s_cnt[0][p * 4 + wave] = c_ini; s_cnt[1][p * 4 + wave] = c_min; }
-        keep_ini |= f_ini << (4 * p);
-        keep_min |= f_min << (4 * p);
     }
     __syncthreads();
-    if (tid < 32) {  // exclusive scan of the 16 (pass, wave) counts, both thresholds
-        const int t = tid >> 4, k = tid & 15;
-        const int v = s_cnt[t][k];
-        int inc = v;
+    if (wave == 0) {  // row counts -> raster offsets; retry at minTh only if iniTh found nothing (:812-816)
+        const int c_ini = __popc(s_rowmask[0][lane][0]) + __popc(s_rowmask[0][lane][1]);
+        const int c_min = __popc(s_rowmask[1][lane][0]) + __popc(s_rowmask[1][lane][1]);
+        int i_ini = c_ini, i_min = c_min;
 #pragma unroll
-        for (int o = 1; o < 16; o <<= 1) { const int u = __shfl_up(inc, o, 16); if (k >= o) inc += u; }
-        s_off[t][k] = inc - v;
-        if (k == 15) s_off[t][16] = inc;
+        for (int o = 1; o < 64; o <<= 1) {
+            const int u = __shfl_up(i_ini, o), v = __shfl_up(i_min, o);
+            if (lane >= o) { i_ini += u; i_min += v; }
+        }
+        const int t_ini = __shfl(i_ini, 63), t_min = __shfl(i_min, 63);
+        const int use = t_ini > 0 ? 0 : 1;
+        s_rowoff[lane] = use == 0 ? i_ini - c_ini : i_min - c_min;
+        if (lane == 0) { s_use = use; s_total = use == 0 ? t_ini : t_min; }
     }
     __syncthreads();
-    const int use = s_off[0][16] > 0 ? 0 : 1;  // retry at minTh only if iniTh found nothing (:812-816)
-    const int total = s_off[use][16];
-    const uint32_t keep = use == 0 ? keep_ini : keep_min;
-    for (int p = 0; p < npass; ++p) {
-        const uint32_t f = (keep >> (4 * p)) & 15;
-        // raster order: items in index order, pixels of an item left to right
-        const int n = __popc(f);
-        int inc = n;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(inc, o); if (lane >= o) inc += u; }
-        if (f) {
-            const int idx = p * 256 + tid;
-            const int y = (int)(((uint32_t)idx * magic) >> 20), g = idx - y * ng;
-            int pos = s_off[use][p * 4 + wave] + inc - n;
-            const uint32_t sc = s_score32[(y + 1) * (PSL_FAST4_SP / 4) + g + 1];
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj)
-                if ((f >> jj) & 1) {
-                    if (pos < P.cellcap)
-                        out[pos] = (uint32_t)(4 * g + jj + 3 + j * L.wCell) | ((uint32_t)(y + 3 + i * L.hCell) << 12) | (((sc >> (8 * jj)) & 255) << 24);
-                    ++pos;
-                }
+    const int use = s_use, total = s_total;
+    for (int k = tid; k < nlist; k += 256) {
+        const int e = s_list[k];
+        const int y = (e >> 6) & 63, x = e & 63;
+        const uint32_t w0 = s_rowmask[use][y][0], w1 = s_rowmask[use][y][1];
+        const uint32_t mine = x < 32 ? (w0 >> x) & 1 : (w1 >> (x - 32)) & 1;
+        if (mine) {
+            const int before = x < 32 ? __popc(w0 & ((1u << x) - 1u)) : __popc(w0) + __popc(w1 & ((1u << (x - 32)) - 1u));
+            const int pos = s_rowoff[y] + before;
+            const uint32_t sc = s_score[(y + 1) * PSL_FAST4_SP + x + 4];
+            if (pos < P.cellcap)
+                out[pos] = (uint32_t)(x + 3 + j * L.wCell) | ((uint32_t)(y + 3 + i * L.hCell) << 12) | (sc << 24);
         }
     }
     if (tid == 0) *out_cnt = total < P.cellcap ? total : P.cellcap;
@@ -839,44 +861,78 @@ __global__ __launch_bounds__(256) void k_blur7(OrbParams P, FrameSrc S, uint8_t*
         }
     }
     __syncthreads();
-    const int K0 = P.blurK[0], K1 = P.blurK[1], K2 = P.blurK[2], K3 = P.blurK[3];
-    for (int k = tid; k < rows * 16; k += 256) {  // row pass: 4 outputs from 10 input bytes
+    // Row pass with packed 16-bit math (row sums fit 16 bits: 255 * 257): P[t] = (v[t], v[t+1]) as two u16 built by
+    // v_perm from the three dwords that hold the 10 input bytes; outputs (o0,o1) = sum K[t] P[t], (o2,o3) = sum K[t] P[t+2].
+    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+    const uint32_t K0 = (uint32_t)P.blurK[0], K1 = (uint32_t)P.blurK[1], K2 = (uint32_t)P.blurK[2], K3 = (uint32_t)P.blurK[3];
+    const u16x2 k0 = __builtin_bit_cast(u16x2, K0 | (K0 << 16)), k1 = __builtin_bit_cast(u16x2, K1 | (K1 << 16));
+    const u16x2 k2 = __builtin_bit_cast(u16x2, K2 | (K2 << 16)), k3 = __builtin_bit_cast(u16x2, K3 | (K3 << 16));
+    for (int k = tid; k < rows * 16; k += 256) {
         const int r = k >> 4, g = k & 15;
-        // output x = x0 + 4g + j reads bytes (4g + j + 1) .. (4g + j + 7) of the row: three aligned dwords
+        // output x = x0 + 4g + j reads stream bytes (4g + j + 1) .. (4g + j + 7) of the row: three aligned dwords
         const uint32_t* in32 = reinterpret_cast<const uint32_t*>(&s_in[r * 72 + g * 4]);
         const uint32_t w0 = in32[0], w1 = in32[1], w2 = in32[2];
-        int v[10];
-        v[0] = (w0 >> 8) & 0xff; v[1] = (w0 >> 16) & 0xff; v[2] = w0 >> 24;
-        v[3] = w1 & 0xff; v[4] = (w1 >> 8) & 0xff; v[5] = (w1 >> 16) & 0xff; v[6] = w1 >> 24;
-        v[7] = w2 & 0xff; v[8] = (w2 >> 8) & 0xff; v[9] = (w2 >> 16) & 0xff;
-        uint16_t o[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            o[j] = (uint16_t)(K0 * (v[j] + v[j + 6]) + K1 * (v[j + 1] + v[j + 5]) + K2 * (v[j + 2] + v[j + 4]) + K3 * v[j + 3]);
-        *reinterpret_cast<uint2*>(&s_row[r * 64 + g * 4]) = make_uint2((uint32_t)o[0] | ((uint32_t)o[1] << 16), (uint32_t)o[2] | ((uint32_t)o[3] << 16));
+        // v[n] = stream byte n + 1; perm(hi, lo, sel): selector bytes 0-3 pick from lo, 4-7 from hi, 0x0c = zero
+#define PSL_PAIR(hi, lo, b0, b1) __builtin_bit_cast(u16x2, __builtin_amdgcn_perm(hi, lo, 0x0c000c00u | (uint32_t)(b0) | ((uint32_t)(b1) << 16)))
+        const u16x2 p0 = PSL_PAIR(w1, w0, 1, 2), p1 = PSL_PAIR(w1, w0, 2, 3), p2 = PSL_PAIR(w1, w0, 3, 4), p3 = PSL_PAIR(w1, w0, 4, 5);
+        const u16x2 p4 = PSL_PAIR(w1, w0, 5, 6), p5 = PSL_PAIR(w1, w0, 6, 7), p6 = PSL_PAIR(w2, w1, 3, 4), p7 = PSL_PAIR(w2, w1, 4, 5);
+        const u16x2 p8 = PSL_PAIR(w2, w1, 5, 6);
+#undef PSL_PAIR
+        const u16x2 o01 = k0 * (p0 + p6) + k1 * (p1 + p5) + k2 * (p2 + p4) + k3 * p3;
+        const u16x2 o23 = k0 * (p2 + p8) + k1 * (p3 + p7) + k2 * (p4 + p6) + k3 * p5;
+        *reinterpret_cast<uint2*>(&s_row[r * 64 + g * 4]) = make_uint2(__builtin_bit_cast(uint32_t, o01), __builtin_bit_cast(uint32_t, o23));
     }
     __syncthreads();
+    // Column pass: a thread makes 4 adjacent pixels of 4 consecutive rows from 10 row-sum rows read once.  Two
+    // vertically adjacent row sums of a pixel are paired into one register (v_perm) and meet their two
+    // coefficients in v_dot2_u32_u16; the 7th tap is a plain multiply-add.  Accumulators start at the rounding
+    // constant 2^15; min(acc, 2^24 - 1) >> 16 is saturate_cast<uchar>((acc) >> 16).
     const int orows = rows - 6;
     uint8_t* dst = blur + (size_t)frame * blur_fstride + L.blur_off;
-    for (int k = tid; k < orows * 16; k += 256) {  // column pass
-        const int oy = k >> 4, g = k & 15;
-        if (x0 + g * 4 >= L.pitch) continue;
-        int acc[4] = {0, 0, 0, 0};
+    const u16x2 c01 = __builtin_bit_cast(u16x2, K0 | (K1 << 16)), c23 = __builtin_bit_cast(u16x2, K2 | (K3 << 16));
+    const u16x2 c45 = __builtin_bit_cast(u16x2, K2 | (K1 << 16));
+    {
+        const int g = tid & 15, oy0 = (tid >> 4) * 4;
+        if (x0 + g * 4 < L.pitch && oy0 < orows) {
+            uint2 q[10];
 #pragma unroll
-        for (int j = 0; j < 7; ++j) {
-            const uint2 q = *reinterpret_cast<const uint2*>(&s_row[(oy + j) * 64 + g * 4]);
-            const int kk = P.blurK[j];
-            acc[0] += kk * (int)(q.x & 0xffff); acc[1] += kk * (int)(q.x >> 16);
-            acc[2] += kk * (int)(q.y & 0xffff); acc[3] += kk * (int)(q.y >> 16);
-        }
-        uint32_t packed = 0;
+            for (int rr = 0; rr < 10; ++rr) q[rr] = *reinterpret_cast<const uint2*>(&s_row[min(oy0 + rr, rows - 1) * 64 + g * 4]);
+            uint32_t acc[4][4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            int v = (acc[j] + (1 << 15)) >> 16;
-            v = v > 255 ? 255 : v;
-            packed |= (uint32_t)v << (8 * j);
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int x = 0; x < 4; ++x) acc[i][x] = 1u << 15;
+#pragma unroll
+            for (int rr = 0; rr < 8; ++rr) {  // pair of rows (rr, rr + 1)
+                const u16x2 a0 = __builtin_bit_cast(u16x2, __builtin_amdgcn_perm(q[rr + 1].x, q[rr].x, 0x05040100u));
+                const u16x2 a1 = __builtin_bit_cast(u16x2, __builtin_amdgcn_perm(q[rr + 1].x, q[rr].x, 0x07060302u));
+                const u16x2 a2 = __builtin_bit_cast(u16x2, __builtin_amdgcn_perm(q[rr + 1].y, q[rr].y, 0x05040100u));
+                const u16x2 a3 = __builtin_bit_cast(u16x2, __builtin_amdgcn_perm(q[rr + 1].y, q[rr].y, 0x07060302u));
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {  // output row oy0 + i uses the pairs starting at i, i + 2, i + 4
+                    const int m = rr - i;
+                    if (m == 0 || m == 2 || m == 4) {
+                        const u16x2 c = m == 0 ? c01 : (m == 2 ? c23 : c45);
+                        acc[i][0] = __builtin_amdgcn_udot2(a0, c, acc[i][0], false);
+                        acc[i][1] = __builtin_amdgcn_udot2(a1, c, acc[i][1], false);
+                        acc[i][2] = __builtin_amdgcn_udot2(a2, c, acc[i][2], false);
+                        acc[i][3] = __builtin_amdgcn_udot2(a3, c, acc[i][3], false);
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (oy0 + i >= orows) break;
+                const uint2 t = q[i + 6];  // 7th tap, coefficient K0
+                acc[i][0] += K0 * (t.x & 0xffff); acc[i][1] += K0 * (t.x >> 16);
+                acc[i][2] += K0 * (t.y & 0xffff); acc[i][3] += K0 * (t.y >> 16);
+                const uint32_t m0 = min(acc[i][0], 0xffffffu), m1 = min(acc[i][1], 0xffffffu);
+                const uint32_t m2 = min(acc[i][2], 0xffffffu), m3 = min(acc[i][3], 0xffffffu);
+                // byte 2 of each -> bytes 0..3
+                const uint32_t lo = __builtin_amdgcn_perm(m1, m0, 0x0c0c0602u), hi = __builtin_amdgcn_perm(m3, m2, 0x06020c0cu);
+                *reinterpret_cast<uint32_t*>(dst + (size_t)(y0 + oy0 + i) * L.pitch + x0 + g * 4) = lo | hi;
+            }
         }
-        *reinterpret_cast<uint32_t*>(dst + (size_t)(y0 + oy) * L.pitch + x0 + g * 4) = packed;
     }
 }
 

@@ -240,7 +240,7 @@ struct pslfe_orb {
                     dim3 grid((P.lv[l].pitch / 4 + 63) / 64, (P.lv[l].h + 3) / 4, F);
                     k_pyr_resize<<<grid, 256, 0, st>>>(P, S, l, d_xofs[l], d_alpha[l], d_yofs[l], d_beta[l]);
                 } else {
-                    dim3 grid((P.lv[l].pitch + 63) / 64, (P.lv[l].h + 15) / 16, F);
+                    dim3 grid((P.lv[l].pitch + 63) / 64, (P.lv[l].h + PSL_PYR_BH - 1) / PSL_PYR_BH, F);
                     k_pyr_resize_tiled<<<grid, 256, 0, st>>>(P, S, l, d_xofs[l], d_alpha[l], d_yofs[l], d_beta[l]);
                 }
             }
