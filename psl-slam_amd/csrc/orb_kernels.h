@@ -407,8 +407,8 @@ __device__ __forceinline__ int psl_fast_score_pol(const uint8_t* c, const int tp
     return A - 1;
 }
 
-__global__ __launch_bounds__(256, 8) void k_fast_cells4(OrbParams P, FrameSrc S, int* __restrict__ cellcnt,
-                                                      uint32_t* __restrict__ cellcand) {
+__global__ __launch_bounds__(256, 8) void k_fast_cells4(OrbParams P, FrameSrc S, const uint32_t* __restrict__ celltab,
+                                                      int* __restrict__ cellcnt, uint32_t* __restrict__ cellcand) {
     __shared__ __attribute__((aligned(16))) uint32_t s_tile32[(PSL_MAXCELL + 6) * (PSL_FAST4_TP / 4) + 4];
     __shared__ __attribute__((aligned(16))) uint32_t s_score32[(PSL_MAXCELL + 2) * (PSL_FAST4_SP / 4)];
     __shared__ uint32_t s_rowmask[2][PSL_MAXCELL][2];  // [iniTh | minTh][row][x >> 5]: NMS survivors
@@ -420,11 +420,9 @@ __global__ __launch_bounds__(256, 8) void k_fast_cells4(OrbParams P, FrameSrc S,
 
     const int cell = blockIdx.x, frame = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    int level = 0;
-    while (level + 1 < P.nlevels && cell >= P.lv[level + 1].cell_off) ++level;
+    const uint32_t ct = celltab[cell];  // level | row << 8 | column << 20 of the cell (host table; one scalar load)
+    const int level = (int)(ct & 0xff), i = (int)((ct >> 8) & 0xfff), j = (int)(ct >> 20);
     const OrbLevelP L = P.lv[level];
-    const int ci = cell - L.cell_off;
-    const int i = ci / L.nCols, j = ci - i * L.nCols;
     int* out_cnt = cellcnt + (size_t)frame * P.ncells + cell;
     uint32_t* out = cellcand + ((size_t)frame * P.ncells + cell) * P.cellcap;
 
@@ -484,26 +482,40 @@ __global__ __launch_bounds__(256, 8) void k_fast_cells4(OrbParams P, FrameSrc S,
             // centre of pixel 4g + jj: tile byte 4(g+1) + jj of tile row y + 3
             const uint32_t* r = &s_tile32[(y + 3) * (PSL_FAST4_TP / 4) + g];
             const uint32_t m0 = r[0], m1 = r[1], m2 = r[2];
-            const uint32_t C = m1, R12 = psl_alignbyte(m1, m0, 1), R4 = psl_alignbyte(m2, m1, 3);
             const uint32_t R0 = r[3 * (PSL_FAST4_TP / 4) + 1], R8 = r[-3 * (PSL_FAST4_TP / 4) + 1];
             const uint32_t* rp = r + 2 * (PSL_FAST4_TP / 4);
             const uint32_t* rm = r - 2 * (PSL_FAST4_TP / 4);
             const uint32_t p0 = rp[0], p1 = rp[1], p2 = rp[2], q0 = rm[0], q1 = rm[1], q2 = rm[2];
-            const uint32_t R14 = psl_alignbyte(p1, p0, 2), R2 = psl_alignbyte(p2, p1, 2);
-            const uint32_t R10 = psl_alignbyte(q1, q0, 2), R6 = psl_alignbyte(q2, q1, 2);
+            // Two pixels per instruction: v_perm lifts the bytes of a pixel pair (byte offsets o, o + 1 of the 8-byte
+            // pool hi:lo) to two u16, packed min/max/add/sub do the test, the sign bits of hi - bmin and dmax - lo are
+            // the two polarity flags.
+            typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+#define PSL_PX2(hi, lo, o) __builtin_bit_cast(u16x2, __builtin_amdgcn_perm(hi, lo, 0x0c000c00u | (uint32_t)(o) | ((uint32_t)((o) + 1) << 16)))
+            const u16x2 t2 = __builtin_bit_cast(u16x2, (uint32_t)minTh * 0x10001u);
+            uint32_t sb[2], sd[2];
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj) {
-                const int sft = 8 * jj;
-                const int c = (C >> sft) & 255, hi = c + minTh, lo = c - minTh;
-                const int r0 = (R0 >> sft) & 255, r8 = (R8 >> sft) & 255, r4 = (R4 >> sft) & 255, r12 = (R12 >> sft) & 255;
-                const int r2 = (R2 >> sft) & 255, r10 = (R10 >> sft) & 255, r6 = (R6 >> sft) & 255, r14 = (R14 >> sft) & 255;
-                const int bmin = min(min(max(r0, r8), max(r4, r12)), min(max(r2, r10), max(r6, r14)));
-                const int dmax = max(max(min(r0, r8), min(r4, r12)), max(min(r2, r10), min(r6, r14)));
-                const bool inside = 4 * g + jj < iw;
-                const uint32_t pb = (uint32_t)((bmin > hi) & inside), pd = (uint32_t)((dmax < lo) & inside);
-                m4 |= (pb | pd) << jj;
-                pol |= (pb | (pd << 1)) << (2 * jj);
+            for (int h = 0; h < 2; ++h) {  // pixels 4g + 2h, 4g + 2h + 1: centre bytes 4 + 2h, 5 + 2h of the pool m1:m0
+                const int o = 2 * h;
+                const u16x2 c = PSL_PX2(m1, m0, 4 + o);
+                const u16x2 r0 = PSL_PX2(0u, R0, o), r8 = PSL_PX2(0u, R8, o);
+                const u16x2 r12 = PSL_PX2(m1, m0, 1 + o), r4 = PSL_PX2(m2, m1, 3 + o);      // centre row, columns -3 / +3
+                const u16x2 r14 = PSL_PX2(p1, p0, 2 + o), r2 = PSL_PX2(p2, p1, 2 + o);      // row +2, columns -2 / +2
+                const u16x2 r10 = PSL_PX2(q1, q0, 2 + o), r6 = PSL_PX2(q2, q1, 2 + o);      // row -2, columns -2 / +2
+                const u16x2 bmin = __builtin_elementwise_min(__builtin_elementwise_min(__builtin_elementwise_max(r0, r8), __builtin_elementwise_max(r4, r12)),
+                                                             __builtin_elementwise_min(__builtin_elementwise_max(r2, r10), __builtin_elementwise_max(r6, r14)));
+                const u16x2 dmax = __builtin_elementwise_max(__builtin_elementwise_max(__builtin_elementwise_min(r0, r8), __builtin_elementwise_min(r4, r12)),
+                                                             __builtin_elementwise_max(__builtin_elementwise_min(r2, r10), __builtin_elementwise_min(r6, r14)));
+                const u16x2 hi = c + t2, lo = c - t2;  // lo wraps below 0: the differences below are read as signed 16 bit
+                sb[h] = __builtin_bit_cast(uint32_t, (u16x2)(hi - bmin)) & 0x80008000u;  // bmin > hi
+                sd[h] = __builtin_bit_cast(uint32_t, (u16x2)(dmax - lo)) & 0x80008000u;  // dmax < lo
             }
+#undef PSL_PX2
+            // polarity bits (2 per pixel): pixel 2h from bit 15, pixel 2h + 1 from bit 31
+            pol = ((sb[0] >> 15) & 0x1u) | ((sd[0] >> 14) & 0x2u) | ((sb[0] >> 29) & 0x4u) | ((sd[0] >> 28) & 0x8u) |
+                  ((sb[1] >> 11) & 0x10u) | ((sd[1] >> 10) & 0x20u) | ((sb[1] >> 25) & 0x40u) | ((sd[1] >> 24) & 0x80u);
+            const int nin = iw - 4 * g;  // pixels of this group inside the cell
+            if (nin < 4) pol &= (1u << (2 * nin)) - 1u;
+            m4 = ((pol | (pol >> 1)) & 0x1u) | (((pol | (pol >> 1)) >> 1) & 0x2u) | (((pol | (pol >> 1)) >> 2) & 0x4u) | (((pol | (pol >> 1)) >> 3) & 0x8u);
         }
         // order inside s_list is irrelevant: one slot range per (wave, jj)
         const unsigned long long b0 = __ballot(m4 & 1), b1 = __ballot(m4 & 2), b2 = __ballot(m4 & 4), b3 = __ballot(m4 & 8);

@@ -88,6 +88,7 @@ struct pslfe_orb {
     PslKeyPoint* d_kps = nullptr;
     uint8_t* d_desc = nullptr;
     int* d_counts = nullptr;
+    uint32_t* d_celltab = nullptr;  // [ncells] level | row << 8 | column << 20
     int* d_xofs[PSLFE_MAX_LEVELS] = {};
     short2* d_alpha[PSLFE_MAX_LEVELS] = {};
     int* d_yofs[PSLFE_MAX_LEVELS] = {};
@@ -104,7 +105,8 @@ struct pslfe_orb {
     void release() {
         hipFree(d_pyr); hipFree(d_blur); hipFree(d_cellcnt); hipFree(d_celloff); hipFree(d_cellcand);
         hipFree(d_cand); hipFree(d_knode); hipFree(d_lvlkp); hipFree(d_lvlcnt); hipFree(d_kps);
-        hipFree(d_desc); hipFree(d_counts); hipFree(d_in);
+        hipFree(d_desc); hipFree(d_counts); hipFree(d_in); hipFree(d_celltab);
+        d_celltab = nullptr;
         d_pyr = d_blur = d_desc = d_in = nullptr;
         d_cellcnt = d_celloff = d_lvlcnt = d_counts = nullptr;
         d_cellcand = d_cand = d_lvlkp = nullptr;
@@ -205,6 +207,14 @@ struct pslfe_orb {
         in_pitch = (int)psl_align_up(w, 16);
         in_fstride = psl_align_up((size_t)in_pitch * h, 256);
         if ((rc = dev_alloc(&d_in, in_fstride * F))) return rc;
+        {
+            std::vector<uint32_t> tab((size_t)Q.ncells);
+            for (int l = 0; l < nlevels; ++l)
+                for (int c = 0; c < Q.lv[l].nCols * Q.lv[l].nRows; ++c)
+                    tab[(size_t)Q.lv[l].cell_off + c] = (uint32_t)l | ((uint32_t)(c / Q.lv[l].nCols) << 8) | ((uint32_t)(c % Q.lv[l].nCols) << 20);
+            if ((rc = dev_alloc(&d_celltab, tab.size()))) return rc;
+            PSL_HIP(hipMemcpy(d_celltab, tab.data(), tab.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        }
         for (int l = 1; l < nlevels; ++l) {
             std::vector<int> xo, yo;
             std::vector<short> al, be;
@@ -249,7 +259,7 @@ struct pslfe_orb {
         {
             PSL_STAGE_BEGIN(ctx, "orb.fast");
             if (fast_v1) k_fast_cells<<<dim3(P.ncells, F), 256, 0, st>>>(P, S, d_cellcnt, d_cellcand);
-            else k_fast_cells4<<<dim3(P.ncells, F), 256, 0, st>>>(P, S, d_cellcnt, d_cellcand);
+            else k_fast_cells4<<<dim3(P.ncells, F), 256, 0, st>>>(P, S, d_celltab, d_cellcnt, d_cellcand);
             PSL_STAGE_END(ctx, "orb.fast");
         }
         {
