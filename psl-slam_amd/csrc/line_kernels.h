@@ -824,7 +824,10 @@ __global__ __launch_bounds__(64) void k_lsd_grow2(LineParams P, const float* __r
 }
 
 
-__global__ __launch_bounds__(64) void k_lsd_grow3(LineParams P, const float* __restrict__ angdeg, const double* __restrict__ modgrad,
+#ifndef PSL_GROW_WAVES
+#define PSL_GROW_WAVES 5   // waves per SIMD the register budget allows; measured: no gain from 7 (spills, throughput-bound)
+#endif
+__global__ __launch_bounds__(64, PSL_GROW_WAVES) void k_lsd_grow3(LineParams P, const float* __restrict__ angdeg, const double* __restrict__ modgrad,
                                                    const float4* __restrict__ trig, uint32_t* __restrict__ usedbits, uint32_t* __restrict__ reg,
                                                    float* __restrict__ seg, int* __restrict__ nseg) {
     __shared__ uint32_t s_ring[PSL_LSD_RING];

@@ -46,7 +46,25 @@ struct FrameSrc {          // where level 0 (the caller's image) and the derived
     size_t fstride0;
     uint8_t* pyr;          // per-frame pyramid block (levels >= 1)
     size_t pyr_fstride;
+    int nframes;
+    int xcd;               // launches use the XCD-aware grid (8, items, ceil(nframes / 8)), see psl_item_frame
 };
+
+// Workgroup -> (item, frame).  The hardware deals consecutive workgroups round-robin to the 8 XCDs, each with its own
+// L2.  With the plain grid (items, frames) the tiles that share cache lines (neighbouring cells / tiles of a level) land
+// on 8 different L2s and every line is fetched from HBM/MALL up to 8 times (measured: 4.6x the algorithmic bytes for
+// FAST).  Many-frames launches therefore use grid (8, items, ceil(frames / 8)): blockIdx.x is the XCD, so all items of
+// a frame run on one XCD, in item order.  Single frames keep the plain grid (all 8 XCDs work on the one frame).
+__device__ __forceinline__ bool psl_item_frame(const FrameSrc& S, int* item, int* frame) {
+    if (S.xcd) {
+        *frame = (int)(blockIdx.z * 8 + blockIdx.x);
+        *item = (int)blockIdx.y;
+        return *frame < S.nframes;
+    }
+    *item = (int)blockIdx.x;
+    *frame = (int)blockIdx.y;
+    return true;
+}
 
 __device__ __forceinline__ const uint8_t* psl_level_ptr(const OrbParams& P, const FrameSrc& S, int level, int frame, int* pitch) {
     if (level == 0) { *pitch = S.stride0; return S.img0 + (size_t)frame * S.fstride0; }
@@ -111,8 +129,12 @@ __global__ __launch_bounds__(256) void k_pyr_resize_tiled(OrbParams P, FrameSrc 
                                                            const int* __restrict__ yofs, const short2* __restrict__ beta) {
     __shared__ uint32_t s_tile[PSL_PYR_TR * PSL_PYR_TD];
     const OrbLevelP L = P.lv[level];
-    const int frame = blockIdx.z, tid = threadIdx.x;
-    const int x0 = blockIdx.x * 64, y0 = blockIdx.y * PSL_PYR_BH;
+    const int tid = threadIdx.x;
+    int item, frame;
+    if (!psl_item_frame(S, &item, &frame)) return;
+    const int nbx = (L.pitch + 63) / 64;
+    const int by = item / nbx, bx = item - by * nbx;
+    const int x0 = bx * 64, y0 = by * PSL_PYR_BH;
     int spitch;
     const uint8_t* src = psl_level_ptr(P, S, level - 1, frame, &spitch);
     const int sw = P.lv[level - 1].w, sh = P.lv[level - 1].h;
@@ -418,7 +440,8 @@ __global__ __launch_bounds__(256, 8) void k_fast_cells4(OrbParams P, FrameSrc S,
     uint8_t* s_tile = reinterpret_cast<uint8_t*>(s_tile32);
     uint8_t* s_score = reinterpret_cast<uint8_t*>(s_score32);
 
-    const int cell = blockIdx.x, frame = blockIdx.y;
+    int cell, frame;
+    if (!psl_item_frame(S, &cell, &frame)) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t ct = celltab[cell];  // level | row << 8 | column << 20 of the cell (host table; one scalar load)
     const int level = (int)(ct & 0xff), i = (int)((ct >> 8) & 0xfff), j = (int)(ct >> 20);
@@ -847,7 +870,9 @@ __device__ __forceinline__ int psl_reflect101(int p, int n) {
 __global__ __launch_bounds__(256) void k_blur7(OrbParams P, FrameSrc S, uint8_t* __restrict__ blur, size_t blur_fstride) {
     __shared__ __attribute__((aligned(16))) uint8_t s_in[(PSL_BLUR_TH + 6) * 72];
     __shared__ __attribute__((aligned(16))) uint16_t s_row[(PSL_BLUR_TH + 6) * 64];
-    const int tile = blockIdx.x, frame = blockIdx.y, tid = threadIdx.x;
+    const int tid = threadIdx.x;
+    int tile, frame;
+    if (!psl_item_frame(S, &tile, &frame)) return;
     int level = 0;
     while (level + 1 < P.nlevels && tile >= P.lv[level + 1].tile_off) ++level;
     const OrbLevelP L = P.lv[level];
@@ -964,9 +989,10 @@ __global__ __launch_bounds__(256) void k_orient_describe(OrbParams P, FrameSrc S
                                                           uint8_t* __restrict__ desc, int* __restrict__ counts) {
     __shared__ uint32_t s_patch[4][37 * PSL_DESC_PD];
     __shared__ uint32_t s_ori[4][31 * PSL_ORI_PD];
-    const int frame = blockIdx.y;
+    int grp, frame;
+    if (!psl_item_frame(S, &grp, &frame)) return;
     const int lane = threadIdx.x & 63;
-    const int slot = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int slot = grp * 4 + (threadIdx.x >> 6);
     const int* lc = lvlcnt + (size_t)frame * P.nlevels;
     int level = -1, idx = slot, total = 0;
     for (int l = 0; l < P.nlevels; ++l) {

@@ -97,6 +97,7 @@ struct pslfe_orb {
     size_t in_fstride = 0;
     int in_pitch = 0;
     bool fast_v1 = getenv("PSLFE_FAST_V1") != nullptr;        // A/B switch for the one-pixel-per-thread FAST kernel
+    bool no_xcd = getenv("PSLFE_NO_XCD") != nullptr;          // A/B switch for the XCD-aware grids
     bool pyr_simple = getenv("PSLFE_PYR_SIMPLE") != nullptr;  // A/B switch for the untiled pyramid kernel
 
     int last_nframes = 0;
@@ -242,7 +243,11 @@ struct pslfe_orb {
         hipStream_t st = ctx->stream;
         FrameSrc S;
         S.img0 = d_gray; S.stride0 = stride; S.fstride0 = frame_stride; S.pyr = d_pyr; S.pyr_fstride = pyr_fstride;
+        S.nframes = nframes;
+        S.xcd = (nframes >= 8 && !no_xcd) ? 1 : 0;
         const unsigned F = (unsigned)nframes;
+        // grid over (items, frames): XCD-aware for many frames (orb_kernels.h: psl_item_frame)
+        auto G = [&](unsigned items) { return S.xcd ? dim3(8, items, (F + 7) / 8) : dim3(items, F); };
         {
             PSL_STAGE_BEGIN(ctx, "orb.pyramid");
             for (int l = 1; l < nlevels; ++l) {
@@ -250,8 +255,8 @@ struct pslfe_orb {
                     dim3 grid((P.lv[l].pitch / 4 + 63) / 64, (P.lv[l].h + 3) / 4, F);
                     k_pyr_resize<<<grid, 256, 0, st>>>(P, S, l, d_xofs[l], d_alpha[l], d_yofs[l], d_beta[l]);
                 } else {
-                    dim3 grid((P.lv[l].pitch + 63) / 64, (P.lv[l].h + PSL_PYR_BH - 1) / PSL_PYR_BH, F);
-                    k_pyr_resize_tiled<<<grid, 256, 0, st>>>(P, S, l, d_xofs[l], d_alpha[l], d_yofs[l], d_beta[l]);
+                    const unsigned nb = (unsigned)(((P.lv[l].pitch + 63) / 64) * ((P.lv[l].h + PSL_PYR_BH - 1) / PSL_PYR_BH));
+                    k_pyr_resize_tiled<<<G(nb), 256, 0, st>>>(P, S, l, d_xofs[l], d_alpha[l], d_yofs[l], d_beta[l]);
                 }
             }
             PSL_STAGE_END(ctx, "orb.pyramid");
@@ -259,7 +264,7 @@ struct pslfe_orb {
         {
             PSL_STAGE_BEGIN(ctx, "orb.fast");
             if (fast_v1) k_fast_cells<<<dim3(P.ncells, F), 256, 0, st>>>(P, S, d_cellcnt, d_cellcand);
-            else k_fast_cells4<<<dim3(P.ncells, F), 256, 0, st>>>(P, S, d_celltab, d_cellcnt, d_cellcand);
+            else k_fast_cells4<<<G(P.ncells), 256, 0, st>>>(P, S, d_celltab, d_cellcnt, d_cellcand);
             PSL_STAGE_END(ctx, "orb.fast");
         }
         {
@@ -272,12 +277,12 @@ struct pslfe_orb {
         }
         {
             PSL_STAGE_BEGIN(ctx, "orb.blur");
-            k_blur7<<<dim3(P.ntiles, F), 256, 0, st>>>(P, S, d_blur, blur_fstride);
+            k_blur7<<<G(P.ntiles), 256, 0, st>>>(P, S, d_blur, blur_fstride);
             PSL_STAGE_END(ctx, "orb.blur");
         }
         {
             PSL_STAGE_BEGIN(ctx, "orb.describe");
-            k_orient_describe<<<dim3((P.out_cap + 3) / 4, F), 256, 0, st>>>(P, S, d_blur, blur_fstride, d_lvlkp, d_lvlcnt, d_kps, d_desc, d_counts);
+            k_orient_describe<<<G((P.out_cap + 3) / 4), 256, 0, st>>>(P, S, d_blur, blur_fstride, d_lvlkp, d_lvlcnt, d_kps, d_desc, d_counts);
             PSL_STAGE_END(ctx, "orb.describe");
         }
         PSL_HIP(hipGetLastError());

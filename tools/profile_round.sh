@@ -1,0 +1,16 @@
+#!/bin/bash
+# Round profile on the GPU box: kernel trace + stats, then FETCH_SIZE and WRITE_SIZE in their own passes
+# (counters only with --kernel-trace).  usage: tools/profile_round.sh <subdir of gpurun_out> <bench args...>
+set -e
+repo=$GRAFT_REPO_ROOT
+out=$repo/gpurun_out/$1; shift
+mkdir -p $out
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats -d $out/trace -o r --output-format csv -- python3 $repo/bench.py "$@" > $out/trace_bench.json 2> $out/trace.err
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $out/fetch -o r --output-format csv -- python3 $repo/bench.py "$@" --no-cpu-baseline > $out/fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $out/write -o r --output-format csv -- python3 $repo/bench.py "$@" --no-cpu-baseline > $out/write.log 2>&1
+if [ -x $repo/tools/pmc_calib/pmc_calib ]; then
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $out/calib_fetch -o r --output-format csv -- $repo/tools/pmc_calib/pmc_calib > $out/calib_fetch.log 2>&1
+  rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $out/calib_write -o r --output-format csv -- $repo/tools/pmc_calib/pmc_calib > $out/calib_write.log 2>&1
+fi
+ls $out
