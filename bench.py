@@ -62,6 +62,33 @@ STAGE_BYTES_PER_FRAME = {
 }
 LINE_BYTES_PER_FRAME = 17040800 + 12800
 
+# stage -> kernels it launches (kernels per step); HBM traffic of a stage = sum over its launches
+STAGE_KERNELS = {
+    "orb.pyramid": [("k_pyr_resize_tiled", NLEVELS - 1)], "orb.fast": [("k_fast_cells4", 1)], "orb.octree": [("k_octree<256>", 1)],
+    "orb.blur": [("k_blur7", 1)], "orb.describe": [("k_orient_describe", 1)],
+    "match.grid": [("k_frame_import", 1), ("k_build_grid", 1)], "match.window": [("k_window_eval", 1), ("k_window_resolve<0, 4096, 1024>", 1)],
+    "line.lsd_scale": [("k_lsd_scale_tiled", 1)], "line.lsd_grad": [("k_lsd_grad", 1)], "line.lsd_grow": [("k_lsd_grow3", 1)],
+    "line.merge": [("k_line_merge", 1)], "line.lbd_pre": [("k_lbd_pre", 1)], "line.lbd": [("k_lbd", 1)], "line.pair": [("k_lil_pair", 1)],
+    "line.match": [("k_line_match_batch", 1)],
+}
+
+
+def pmc_traffic(workload, stage, batch):
+    """HBM bytes per launch of a stage from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json, written by
+    tools/summarize_round.py: FETCH_SIZE / WRITE_SIZE in their own passes, corrected with the calibration measured in
+    the same session).  None when no pass exists for this workload at this batch size."""
+    try:
+        j = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))[workload]
+        if j["frames_per_launch"] != batch:
+            return None, None
+        total = 0.0
+        for kern, n in STAGE_KERNELS[stage]:
+            k = j["kernels"][kern]
+            total += n * (k["read_bytes"] + k["write_bytes"])
+        return int(total), f"profiles/{j['tag']}_pmc_summary.txt"
+    except Exception:
+        return None, None
+
 
 def synth_batch(batch, seed, n_distinct=16, style="desk"):
     import synth_frames as sf
@@ -260,6 +287,7 @@ def main():
         dom_bytes = STAGE_BYTES_PER_FRAME[dom] * B
         dom_s = stages[dom]["ms_per_launch"] * 1e-3
         achieved = dom_bytes / dom_s / 1e9
+        traffic, traffic_src = pmc_traffic(args.workload, dom, B)
         per_frame = ORB_BYTES_PER_FRAME + MATCH_BYTES_PER_FRAME + (LINE_BYTES_PER_FRAME if LINES else 0)
         out = {
             "metric": "frames/sec ORB+line extract+match, 640x480" if LINES else "frames/sec ORB extract+match, 640x480",
@@ -273,7 +301,7 @@ def main():
                        "frames_per_step_per_gpu": B, "mean_keypoints": round(mean_kp, 1), "mean_matches": round(mean_matches, 1),
                        "multi_gpu": "independent stream per rank, RCCL all-gather of result records" if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": dom_bytes, "ms_per_launch": round(stages[dom]["ms_per_launch"], 4)},
             "pipeline_roofline": {"bytes_per_frame": per_frame,
                                   "achieved_GBs": round(fps / world * per_frame / 1e9, 2),

@@ -357,9 +357,9 @@ __global__ __launch_bounds__(256) void k_line_merge(LineParams P, MergeScratch M
 // reflecting the blurred image because the kernel is symmetric.  Output: interleaved (dx, dy) as short2.
 __global__ __launch_bounds__(256) void k_lbd_pre(LineParams P, const uint8_t* __restrict__ gray, int stride, size_t fstride,
                                                   short2* __restrict__ dxy) {
-    __shared__ __attribute__((aligned(16))) uint8_t s_in[38 * 72];
-    __shared__ uint16_t s_row[38 * 68];
-    __shared__ uint8_t s_bl[34 * 68];
+    __shared__ __attribute__((aligned(16))) uint8_t s_in[38 * 72 + 16];
+    __shared__ __attribute__((aligned(16))) uint16_t s_row[38 * 68 + 8];
+    __shared__ __attribute__((aligned(16))) uint8_t s_bl[34 * 68 + 8];
     const int frame = blockIdx.z, tid = threadIdx.x;
     const int x0 = blockIdx.x * 64, y0 = blockIdx.y * 32;
     const uint8_t* img = gray + (size_t)frame * fstride;
@@ -378,29 +378,103 @@ __global__ __launch_bounds__(256) void k_lbd_pre(LineParams P, const uint8_t* __
         }
     }
     __syncthreads();
-    const int K0 = P.lbdK[0], K1 = P.lbdK[1], K2 = P.lbdK[2];
-    for (int k = tid; k < 38 * 66; k += 256) {  // row pass at blurred columns x0-1 .. x0+64 (index j = 0..65)
-        const int r = k / 66, j = k - r * 66;
-        const uint8_t* in = &s_in[r * 72 + j + 1];  // blurred column x0-1+j reads input x0-3+j .. x0+1+j = c (j+1)..(j+5)
-        s_row[r * 68 + j] = (uint16_t)(K0 * (in[0] + in[4]) + K1 * (in[1] + in[3]) + K2 * in[2]);
+    // The kernel was LDS-bound with one byte / u16 read per tap.  Same integer arithmetic, four adjacent outputs per
+    // thread from aligned dwords: the row pass in packed 16-bit math (row sums fit 16 bits: 255 * 257), the column
+    // pass with v_dot2_u32_u16 on vertically paired row sums, Sobel from six dwords per four pixels.
+    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+    const uint32_t K0 = (uint32_t)P.lbdK[0], K1 = (uint32_t)P.lbdK[1], K2 = (uint32_t)P.lbdK[2];
+    {
+        const u16x2 k0 = __builtin_bit_cast(u16x2, K0 * 0x10001u), k1 = __builtin_bit_cast(u16x2, K1 * 0x10001u), k2 = __builtin_bit_cast(u16x2, K2 * 0x10001u);
+        // row pass at blurred columns x0-1 .. x0+64 (index j = 0..65; groups of 4, the last group's extra columns unused):
+        // blurred column j reads input bytes (j+1)..(j+5) of the row
+        for (int k = tid; k < 38 * 17; k += 256) {
+            const int r = k / 17, g = k - r * 17;
+            const uint32_t* in32 = reinterpret_cast<const uint32_t*>(&s_in[r * 72 + 4 * g]);
+            const uint32_t w0 = in32[0], w1 = in32[1], w2 = in32[2];
+#define PSL_PAIR(hi, lo, b0, b1) __builtin_bit_cast(u16x2, __builtin_amdgcn_perm(hi, lo, 0x0c000c00u | (uint32_t)(b0) | ((uint32_t)(b1) << 16)))
+            const u16x2 p0 = PSL_PAIR(w1, w0, 1, 2), p1 = PSL_PAIR(w1, w0, 2, 3), p2 = PSL_PAIR(w1, w0, 3, 4), p3 = PSL_PAIR(w1, w0, 4, 5);
+            const u16x2 p4 = PSL_PAIR(w1, w0, 5, 6), p5 = PSL_PAIR(w1, w0, 6, 7), p6 = PSL_PAIR(w2, w1, 3, 4);
+#undef PSL_PAIR
+            const u16x2 o01 = k0 * (p0 + p4) + k1 * (p1 + p3) + k2 * p2;
+            const u16x2 o23 = k0 * (p2 + p6) + k1 * (p3 + p5) + k2 * p4;
+            *reinterpret_cast<uint2*>(&s_row[r * 68 + 4 * g]) = make_uint2(__builtin_bit_cast(uint32_t, o01), __builtin_bit_cast(uint32_t, o23));
+        }
     }
     __syncthreads();
-    for (int k = tid; k < 34 * 66; k += 256) {  // column pass at blurred rows y0-1 .. y0+32 (index r = 0..33)
-        const int r = k / 66, j = k - r * 66;
-        const uint16_t* rs = &s_row[r * 68 + j];  // blurred row y0-1+r reads input rows y0-3+r .. = s_row rows r .. r+4
-        const int sum = K0 * ((int)rs[0] + (int)rs[4 * 68]) + K1 * ((int)rs[68] + (int)rs[3 * 68]) + K2 * (int)rs[2 * 68];
-        const int v = (sum + (1 << 15)) >> 16;
-        s_bl[r * 68 + j] = (uint8_t)(v > 255 ? 255 : v);
+    {
+        // column pass at blurred rows y0-1 .. y0+32 (index r = 0..33): row r reads row sums r .. r+4.  A thread makes
+        // 4 columns x 4 rows from 8 row-sum rows.
+        const u16x2 c01 = __builtin_bit_cast(u16x2, K0 | (K1 << 16)), c23 = __builtin_bit_cast(u16x2, K2 | (K1 << 16));
+        for (int k = tid; k < 9 * 17; k += 256) {
+            const int st = k / 17, g = k - st * 17;
+            const int r0 = st * 4;
+            uint2 q[8];
+#pragma unroll
+            for (int rr = 0; rr < 8; ++rr) q[rr] = *reinterpret_cast<const uint2*>(&s_row[min(r0 + rr, 37) * 68 + 4 * g]);
+            uint32_t acc[4][4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int x = 0; x < 4; ++x) acc[i][x] = 1u << 15;
+#pragma unroll
+            for (int rr = 0; rr < 6; ++rr) {  // pair of rows (rr, rr + 1)
+                const u16x2 a0 = __builtin_bit_cast(u16x2, __builtin_amdgcn_perm(q[rr + 1].x, q[rr].x, 0x05040100u));
+                const u16x2 a1 = __builtin_bit_cast(u16x2, __builtin_amdgcn_perm(q[rr + 1].x, q[rr].x, 0x07060302u));
+                const u16x2 a2 = __builtin_bit_cast(u16x2, __builtin_amdgcn_perm(q[rr + 1].y, q[rr].y, 0x05040100u));
+                const u16x2 a3 = __builtin_bit_cast(u16x2, __builtin_amdgcn_perm(q[rr + 1].y, q[rr].y, 0x07060302u));
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {  // output row r0 + i uses the pairs starting at i (K0,K1) and i + 2 (K2,K1)
+                    const int m = rr - i;
+                    if (m == 0 || m == 2) {
+                        const u16x2 c = m == 0 ? c01 : c23;
+                        acc[i][0] = __builtin_amdgcn_udot2(a0, c, acc[i][0], false);
+                        acc[i][1] = __builtin_amdgcn_udot2(a1, c, acc[i][1], false);
+                        acc[i][2] = __builtin_amdgcn_udot2(a2, c, acc[i][2], false);
+                        acc[i][3] = __builtin_amdgcn_udot2(a3, c, acc[i][3], false);
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (r0 + i >= 34) break;
+                const uint2 t = q[i + 4];  // 5th tap, coefficient K0
+                acc[i][0] += K0 * (t.x & 0xffff); acc[i][1] += K0 * (t.x >> 16);
+                acc[i][2] += K0 * (t.y & 0xffff); acc[i][3] += K0 * (t.y >> 16);
+                const uint32_t m0 = min(acc[i][0], 0xffffffu), m1 = min(acc[i][1], 0xffffffu);
+                const uint32_t m2 = min(acc[i][2], 0xffffffu), m3 = min(acc[i][3], 0xffffffu);
+                const uint32_t lo = __builtin_amdgcn_perm(m1, m0, 0x0c0c0602u), hi = __builtin_amdgcn_perm(m3, m2, 0x06020c0cu);
+                *reinterpret_cast<uint32_t*>(&s_bl[(r0 + i) * 68 + 4 * g]) = lo | hi;
+            }
+        }
     }
     __syncthreads();
-    for (int k = tid; k < 32 * 64; k += 256) {  // Sobel 3x3
-        const int oy = k >> 6, ox = k & 63;
-        const int x = x0 + ox, y = y0 + oy;
+    for (int k = tid; k < 32 * 16; k += 256) {  // Sobel 3x3, 4 pixels per thread: blurred bytes 4g .. 4g+5 of three rows
+        const int oy = k >> 4, g = k & 15;
+        const int x = x0 + 4 * g, y = y0 + oy;
         if (x >= P.w || y >= P.h) continue;
-        const uint8_t* b = &s_bl[(oy + 1) * 68 + ox + 1];
-        const int a00 = b[-68 - 1], a01 = b[-68], a02 = b[-68 + 1], a10 = b[-1], a12 = b[1], a20 = b[68 - 1], a21 = b[68], a22 = b[68 + 1];
-        dxy[(size_t)frame * P.w * P.h + (size_t)y * P.w + x] =
-            make_short2((short)((a02 + 2 * a12 + a22) - (a00 + 2 * a10 + a20)), (short)((a20 + 2 * a21 + a22) - (a00 + 2 * a01 + a02)));
+        int c[3][6];
+#pragma unroll
+        for (int rr = 0; rr < 3; ++rr) {
+            const uint32_t* b32 = reinterpret_cast<const uint32_t*>(&s_bl[(oy + rr) * 68 + 4 * g]);
+            const uint32_t w0 = b32[0], w1 = b32[1];
+            c[rr][0] = w0 & 255; c[rr][1] = (w0 >> 8) & 255; c[rr][2] = (w0 >> 16) & 255; c[rr][3] = w0 >> 24;
+            c[rr][4] = w1 & 255; c[rr][5] = (w1 >> 8) & 255;
+        }
+        short2 o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int a00 = c[0][j], a01 = c[0][j + 1], a02 = c[0][j + 2], a10 = c[1][j], a12 = c[1][j + 2], a20 = c[2][j], a21 = c[2][j + 1], a22 = c[2][j + 2];
+            o[j] = make_short2((short)((a02 + 2 * a12 + a22) - (a00 + 2 * a10 + a20)), (short)((a20 + 2 * a21 + a22) - (a00 + 2 * a01 + a02)));
+        }
+        short2* dst = dxy + (size_t)frame * P.w * P.h + (size_t)y * P.w + x;
+        if ((P.w & 3) == 0 && x + 3 < P.w) {
+            *reinterpret_cast<uint4*>(dst) = make_uint4(__builtin_bit_cast(uint32_t, o[0]), __builtin_bit_cast(uint32_t, o[1]),
+                                                        __builtin_bit_cast(uint32_t, o[2]), __builtin_bit_cast(uint32_t, o[3]));
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (x + j < P.w) dst[j] = o[j];
+        }
     }
 }
 
