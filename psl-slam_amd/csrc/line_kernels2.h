@@ -512,19 +512,31 @@ __global__ __launch_bounds__(256) void k_lbd(LineParams P, const short2* __restr
         for (int hh = 0; hh < lane; ++hh) { sCorX0 = PSL_FSUB(sCorX0, dL1); sCorY0 = PSL_FADD(sCorY0, dL0); }
         float sCorX = sCorX0, sCorY = sCorY0;
         float pL = 0, nL = 0, pO = 0, nO = 0;
-        for (short wID = 0; wID < lengthOfLSP; wID++) {
-            short t = (short)__builtin_roundf(sCorX);
-            const short xCor = (t < 0) ? 0 : (t > imageWidth) ? imageWidth : t;
-            t = (short)__builtin_roundf(sCorY);
-            const short yCor = (t < 0) ? 0 : (t > imageHeight) ? imageHeight : t;
-            const short2 g2 = pdxy[(int)yCor * realWidth + xCor];
-            const float gx = (float)g2.x, gy = (float)g2.y;
-            const float gDL = PSL_FADD(PSL_FMUL(gx, dL0), PSL_FMUL(gy, dL1));
-            const float gDO = PSL_FADD(PSL_FMUL(gx, dO0), PSL_FMUL(gy, dO1));
-            if (gDL > 0) pL = PSL_FADD(pL, gDL); else nL = PSL_FSUB(nL, gDL);
-            if (gDO > 0) pO = PSL_FADD(pO, gDO); else nO = PSL_FSUB(nO, gDO);
-            sCorX = PSL_FADD(sCorX, dL0);
-            sCorY = PSL_FADD(sCorY, dL1);
+        // The gathers of a row do not depend on each other: fetch 8 samples ahead (the coordinate chain is plain
+        // float adds), then accumulate them in the reference's order.  One sample per wait made the kernel
+        // latency-bound (90 % of the wave cycles in s_waitcnt).
+        for (int w0 = 0; w0 < (int)lengthOfLSP; w0 += 8) {
+            short2 g8[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                short t = (short)__builtin_roundf(sCorX);
+                const short xCor = (t < 0) ? 0 : (t > imageWidth) ? imageWidth : t;
+                t = (short)__builtin_roundf(sCorY);
+                const short yCor = (t < 0) ? 0 : (t > imageHeight) ? imageHeight : t;
+                g8[u] = pdxy[(int)yCor * realWidth + xCor];  // coordinates are clamped: reads past the line's end are harmless
+                sCorX = PSL_FADD(sCorX, dL0);
+                sCorY = PSL_FADD(sCorY, dL1);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (w0 + u < (int)lengthOfLSP) {
+                    const float gx = (float)g8[u].x, gy = (float)g8[u].y;
+                    const float gDL = PSL_FADD(PSL_FMUL(gx, dL0), PSL_FMUL(gy, dL1));
+                    const float gDO = PSL_FADD(PSL_FMUL(gx, dO0), PSL_FMUL(gy, dO1));
+                    if (gDL > 0) pL = PSL_FADD(pL, gDL); else nL = PSL_FSUB(nL, gDL);
+                    if (gDO > 0) pO = PSL_FADD(pO, gDO); else nO = PSL_FSUB(nO, gDO);
+                }
+            }
         }
         const float coef = P.gaussG[lane];
         pL = PSL_FMUL(coef, pL); nL = PSL_FMUL(coef, nL); pO = PSL_FMUL(coef, pO); nO = PSL_FMUL(coef, nO);
