@@ -883,23 +883,36 @@ __global__ __launch_bounds__(64, PSL_GROW_WAVES) void k_lsd_grow3(LineParams P, 
             a4[q] = ad < scan_end ? F.ang[ad] : PSL_LSD_NOTDEF;
             u4[q] = ad < scan_end ? lsdg_word(F, ad >> 5) : 0xffffffffu;
         }
-        bool grown = false;  // a region was grown since the used words of this chunk were loaded
+        // The bitmap changes only through the regions grown here: after each processed seed the remaining candidates
+        // of the 64-pixel row are reconciled with ONE bitmap read per lane (not one read + round trip per candidate),
+        // and the rows further down the chunk are re-read when their turn comes.  A pixel a region took and its
+        // refinement released again is still a candidate, as in the reference's raster scan.
+        bool stale = false;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int ad = base + q * 64 + lane;
+            if (stale) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                u4[q] = ad < scan_end ? lsdg_word(F, ad >> 5) : 0xffffffffu;
+            }
             unsigned long long mask = __ballot(a4[q] != PSL_LSD_NOTDEF && !((u4[q] >> (ad & 31)) & 1u));
+            bool dirty = false;
             while (mask) {
+                if (dirty) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    const uint32_t w = ad < scan_end ? lsdg_word(F, ad >> 5) : 0xffffffffu;
+                    mask &= __ballot(!((w >> (ad & 31)) & 1u));
+                    dirty = false;
+                    if (!mask) break;
+                }
                 const int s = __ffsll((long long)mask) - 1;
                 mask &= mask - 1;
                 const int adx = base + q * 64 + s;
-                if (grown) {
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    if (lsdg_used(F, adx)) continue;
-                }
                 const int y = adx / P.W, x = adx - y * P.W;
                 double reg_angle;
                 int reg_size = lsdg_region_grow(F, x, y, &reg_angle, P.prec);
-                grown = true;
+                stale = true;
+                dirty = true;
                 if (reg_size < P.min_reg_size) continue;
                 LsdRect rec;
                 lsdw_region2rect(F, reg_size, reg_angle, P.prec, &rec);
