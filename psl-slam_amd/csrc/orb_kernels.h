@@ -668,7 +668,13 @@ __global__ __launch_bounds__(BS) void k_octree(OrbParams P, const int* __restric
     uint32_t* keys = cand + (size_t)frame * P.cand_total + L.cand_off;
     uint16_t* kn = knode + (size_t)frame * P.cand_total + L.cand_off;
 
-    // ---- step 0: concatenate the cell lists in cell row-major order (== vToDistributeKeys order)
+    // ---- step 0: concatenate the cell lists in cell row-major order (== vToDistributeKeys order).  Offsets by a block
+    // scan over the cells, kept in LDS (aliasing s_rect, which is not live yet); then thread = candidate: its cell by
+    // binary search in the offsets, so the reads of all candidates are independent and several are in flight per
+    // thread (walking the cells one after another put two dependent round trips per cell on the critical path: 40 %
+    // of the kernel, measured with s_memtime).
+    int* s_off = reinterpret_cast<int*>(&s_rect[0][0]);  // 2 * BS short4 = 4 * BS ints
+    const bool offlds = ncell <= 4 * BS;
     if (tid == 0) s_misc[2] = 0;
     __syncthreads();
     for (int base = 0; base < ncell; base += BS) {
@@ -676,17 +682,36 @@ __global__ __launch_bounds__(BS) void k_octree(OrbParams P, const int* __restric
         const int v = c < ncell ? ccnt_g[c] : 0;
         int tot;
         const int ex = psl_block_excl_scan<BS>(v, s_w, &tot);
-        if (c < ncell) coff_g[c] = s_misc[2] + ex;
+        if (c < ncell) {
+            const int o = s_misc[2] + ex;
+            coff_g[c] = o;
+            if (offlds) s_off[c] = o;
+        }
         __syncthreads();
         if (tid == 0) s_misc[2] += tot;
         __syncthreads();
     }
     int K = s_misc[2];
     if (K > L.cand_cap) K = L.cand_cap;  // cannot happen: cand_cap = sum of the cell capacities
-    for (int c = tid >> 6; c < ncell; c += BS / 64) {
-        const int n = ccnt_g[c], o = coff_g[c];
-        for (int t = tid & 63; t < n; t += 64)
-            if (o + t < K) keys[o + t] = ccand_g[(size_t)c * P.cellcap + t];
+    for (int k0 = tid; k0 < K; k0 += 4 * BS) {
+        uint32_t v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = k0 + u * BS;
+            v[u] = 0;
+            if (k < K) {
+                int lo = 0, hi = ncell;  // first cell whose offset exceeds k; the cell before it holds candidate k
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if ((offlds ? s_off[mid] : coff_g[mid]) > k) hi = mid; else lo = mid + 1;
+                }
+                const int cell = lo - 1;
+                v[u] = ccand_g[(size_t)cell * P.cellcap + (k - (offlds ? s_off[cell] : coff_g[cell]))];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (k0 + u * BS < K) keys[k0 + u * BS] = v[u];
     }
     __syncthreads();
 
