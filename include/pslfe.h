@@ -77,6 +77,10 @@ int pslfe_ctx_synchronize(pslfe_ctx* ctx);
  * number of launches of a stage name ("orb.pyramid", "orb.fast", "orb.octree", "orb.blur",
  * "orb.describe", "match.window", "match.knn2", ...) and resets nothing. */
 int pslfe_ctx_profile(pslfe_ctx* ctx, int enable);
+/* Restrict the timing to one stage (NULL or "" = all stages).  Every timed stage puts two event records
+ * between kernels (~10 us of idle GPU each on MI355X); timing only the stage of interest keeps a
+ * throughput measurement undisturbed. */
+int pslfe_ctx_profile_only(pslfe_ctx* ctx, const char* stage);
 int pslfe_ctx_profile_reset(pslfe_ctx* ctx);
 int pslfe_ctx_stage_time(pslfe_ctx* ctx, const char* stage, double* ms_total, int* launches);
 

@@ -88,6 +88,9 @@ class Context:
     def profile(self, enable=True):
         _check(lib().pslfe_ctx_profile(self._h, C.c_int(1 if enable else 0)), "pslfe_ctx_profile")
 
+    def profile_only(self, stage=None):
+        _check(lib().pslfe_ctx_profile_only(self._h, None if not stage else stage.encode()), "pslfe_ctx_profile_only")
+
     def profile_reset(self):
         _check(lib().pslfe_ctx_profile_reset(self._h), "pslfe_ctx_profile_reset")
 

@@ -116,6 +116,14 @@ int pslfe_ctx_profile(pslfe_ctx* ctx, int enable) {
     return PSLFE_OK;
 }
 
+int pslfe_ctx_profile_only(pslfe_ctx* ctx, const char* stage) {
+    PSL_REQUIRE(ctx, PSLFE_E_INVALID, "pslfe_ctx_profile_only: ctx is NULL");
+    int rc = pslfe_ctx_synchronize(ctx);
+    if (rc) return rc;
+    ctx->profile_only = stage ? stage : "";
+    return PSLFE_OK;
+}
+
 int pslfe_ctx_profile_reset(pslfe_ctx* ctx) {
     PSL_REQUIRE(ctx, PSLFE_E_INVALID, "pslfe_ctx_profile_reset: ctx is NULL");
     int rc = pslfe_ctx_synchronize(ctx);

@@ -41,6 +41,7 @@ struct pslfe_ctx {
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;  // stream in use (own or external)
     bool profile = false;
+    std::string profile_only;  // non-empty: only this stage is timed (two events per step instead of two per stage)
     std::map<std::string, StageTimer> stages;
     // event pool for profile mode: (start, stop, stage) triples resolved at synchronize
     struct Pending { hipEvent_t a, b; std::string stage; };
@@ -55,12 +56,13 @@ struct pslfe_ctx {
 // RAII-less helper used as: PSL_STAGE_BEGIN(ctx,"orb.fast"); launch...; PSL_STAGE_END(ctx,"orb.fast");
 #define PSL_STAGE_BEGIN(ctx, name)                                  \
     hipEvent_t ev_a_ = nullptr, ev_b_ = nullptr;                    \
-    if ((ctx)->profile) {                                           \
+    const bool ev_on_ = (ctx)->profile && ((ctx)->profile_only.empty() || (ctx)->profile_only == (name)); \
+    if (ev_on_) {                                                   \
         int rc_ = (ctx)->stage_begin(name, &ev_a_, &ev_b_);         \
         if (rc_) return rc_;                                        \
     }
 #define PSL_STAGE_END(ctx, name)                                    \
-    if ((ctx)->profile) {                                           \
+    if (ev_on_) {                                                   \
         int rc_ = (ctx)->stage_end(name, ev_a_, ev_b_);             \
         if (rc_) return rc_;                                        \
     }
