@@ -55,7 +55,7 @@ STAGE_BYTES_PER_FRAME = {
     "line.lsd_grad": 8 * 196608 + 2 * 8 * 196608,      # working image read + angle & modgrad write
     "line.lsd_grow": 2 * 8 * 196608 + 2 * 8 * 196608 + 393216,  # angle & modgrad read + coordinate list w+r + used map
     "line.merge": 2 * 16 * 500,
-    "line.lbd_pre": WH + WH + 4 * WH,                  # gray read, blur write, Sobel dx,dy s16 write
+    "line.lbd_pre": WH + 4 * WH,                       # gray read, Sobel (dx, dy) s16 write (the blurred image stays in LDS)
     "line.lbd": 5040000 + 20000,                       # LSR gathers + outputs
     "line.pair": 2 * 16 * 200,
     "line.match": 12800,

@@ -34,6 +34,19 @@ struct LineParams {
     float gaussG[63], gaussL[21];
 };
 
+// Tile -> (tx, ty, frame).  Many-frames launches use the XCD-aware grid (8, tiles, ceil(frames / 8)) so that all tiles
+// of a frame share one L2 (see orb_kernels.h: psl_item_frame); otherwise the plain grid (tiles_x, tiles_y, frames).
+__device__ __forceinline__ bool psl_tile_frame(int tiles_x, int nframes, int xcd, int* tx, int* ty, int* frame) {
+    if (xcd) {
+        *frame = (int)(blockIdx.z * 8 + blockIdx.x);
+        *ty = (int)blockIdx.y / tiles_x;
+        *tx = (int)blockIdx.y - *ty * tiles_x;
+        return *frame < nframes;
+    }
+    *tx = (int)blockIdx.x; *ty = (int)blockIdx.y; *frame = (int)blockIdx.z;
+    return true;
+}
+
 __device__ __forceinline__ int psl_reflect101i(int p, int n) {
     if (n == 1) return 0;
     while (p < 0 || p >= n) p = p < 0 ? -p : 2 * n - 2 - p;
@@ -113,12 +126,14 @@ __device__ __forceinline__ void psl_lsd_src(int d, int ssize, int* s, float* f, 
 }
 
 __global__ __launch_bounds__(256) void k_lsd_scale_tiled(LineParams P, const uint8_t* __restrict__ gray, int stride, size_t fstride,
-                                                          double* __restrict__ scaled) {
+                                                          double* __restrict__ scaled, int nframes, int xcd) {
     __shared__ __attribute__((aligned(16))) uint8_t s_in[PSL_LS_IR * PSL_LS_IC + 16];
     __shared__ double s_rs[PSL_LS_IR * PSL_LS_BC];
     __shared__ double s_bl[PSL_LS_BR * PSL_LS_BC];
-    const int frame = blockIdx.z, tid = threadIdx.x;
-    const int dx0 = blockIdx.x * 64, dy0 = blockIdx.y * 16;
+    const int tid = threadIdx.x;
+    int tx, ty, frame;
+    if (!psl_tile_frame((P.W + 63) / 64, nframes, xcd, &tx, &ty, &frame)) return;
+    const int dx0 = tx * 64, dy0 = ty * 16;
     const uint8_t* img = gray + (size_t)frame * fstride;
     // blurred sample range of this tile
     int s, bx0, bx1, by0, by1;

@@ -356,12 +356,14 @@ __global__ __launch_bounds__(256) void k_line_merge(LineParams P, MergeScratch M
 // LDS.  Blur values in the 1-px halo of the image border are computed from reflected input, which equals
 // reflecting the blurred image because the kernel is symmetric.  Output: interleaved (dx, dy) as short2.
 __global__ __launch_bounds__(256) void k_lbd_pre(LineParams P, const uint8_t* __restrict__ gray, int stride, size_t fstride,
-                                                  short2* __restrict__ dxy) {
+                                                  short2* __restrict__ dxy, int nframes, int xcd) {
     __shared__ __attribute__((aligned(16))) uint8_t s_in[38 * 72 + 16];
     __shared__ __attribute__((aligned(16))) uint16_t s_row[38 * 68 + 8];
     __shared__ __attribute__((aligned(16))) uint8_t s_bl[34 * 68 + 8];
-    const int frame = blockIdx.z, tid = threadIdx.x;
-    const int x0 = blockIdx.x * 64, y0 = blockIdx.y * 32;
+    const int tid = threadIdx.x;
+    int tx, ty, frame;
+    if (!psl_tile_frame((P.w + 63) / 64, nframes, xcd, &tx, &ty, &frame)) return;
+    const int x0 = tx * 64, y0 = ty * 32;
     const uint8_t* img = gray + (size_t)frame * fstride;
     // s_in[r][c] = pixel (x0 - 4 + c, y0 - 3 + r), c in [0, 72): columns x0-3 .. x0+66 are needed (c = 1 .. 70)
     const bool fast = x0 >= 4 && x0 + 68 <= P.w && ((reinterpret_cast<uintptr_t>(img) | (uintptr_t)stride) & 3) == 0;

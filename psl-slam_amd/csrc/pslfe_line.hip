@@ -162,7 +162,11 @@ struct pslfe_line {
             if (getenv("PSLFE_LSD_SCALE_SIMPLE"))
                 k_lsd_scale<<<grid, 256, 0, st>>>(P, d_gray, stride, frame_stride, d_scaled);
             else
-                k_lsd_scale_tiled<<<dim3((P.W + 63) / 64, (P.H + 15) / 16, F), 256, 0, st>>>(P, d_gray, stride, frame_stride, d_scaled);
+            {
+                const unsigned tx = (P.W + 63) / 64, ty = (P.H + 15) / 16;
+                const int xcd = F >= 8 ? 1 : 0;
+                k_lsd_scale_tiled<<<xcd ? dim3(8, tx * ty, (F + 7) / 8) : dim3(tx, ty, F), 256, 0, st>>>(P, d_gray, stride, frame_stride, d_scaled, (int)F, xcd);
+            }
             PSL_STAGE_END(ctx, "line.lsd_scale");
         }
         {
@@ -205,7 +209,9 @@ struct pslfe_line {
         hipStream_t st = ctx->stream;
         {
             PSL_STAGE_BEGIN(ctx, "line.lbd_pre");
-            k_lbd_pre<<<dim3((P.w + 63) / 64, (P.h + 31) / 32, nframes), 256, 0, st>>>(P, d_gray, stride, frame_stride, d_dxy);
+            const unsigned tx = (P.w + 63) / 64, ty = (P.h + 31) / 32;
+            const int xcd = nframes >= 8 ? 1 : 0;
+            k_lbd_pre<<<xcd ? dim3(8, tx * ty, (nframes + 7) / 8) : dim3(tx, ty, nframes), 256, 0, st>>>(P, d_gray, stride, frame_stride, d_dxy, nframes, xcd);
             PSL_STAGE_END(ctx, "line.lbd_pre");
         }
         {

@@ -98,6 +98,24 @@ public:
         check(pslfe_frame_set(h_, slot, keysUn.data(), descriptors.data(), uRight, (int)keysUn.size(), mnMinX, mnMinY, mnMaxX, mnMaxY),
               "pslfe_frame_set");
     }
+    // The RGB-D part of the Frame constructor (src/Frame.cc:105-171): UndistortKeyPoints, ComputeStereoFromRGBD,
+    // ComputeImageBounds and AssignFeaturesToGrid from the raw keypoints and the CV_32F depth image.
+    void setRGBD(int slot, const std::vector<PslKeyPoint>& keys, const std::vector<uint8_t>& descriptors, const float* depth, int cols,
+                 int rows, int strideFloats, const PslCamera& cam) {
+        check(pslfe_frame_set_rgbd(h_, slot, keys.data(), descriptors.data(), (int)keys.size(), depth, cols, rows, strideFloats, &cam),
+              "pslfe_frame_set_rgbd");
+    }
+    // mvKeysUn, mvDepth, mvuRight of a slot
+    void fetch(int slot, std::vector<PslKeyPoint>& keysUn, std::vector<float>& depth, std::vector<float>& uRight, int capacity) {
+        keysUn.resize(capacity); depth.resize(capacity); uRight.resize(capacity);
+        int n = 0;
+        check(pslfe_frame_fetch(h_, slot, keysUn.data(), depth.data(), uRight.data(), capacity, &n), "pslfe_frame_fetch");
+        keysUn.resize(n); depth.resize(n); uRight.resize(n);
+    }
+    // mnMinX, mnMinY, mnMaxX, mnMaxY (src/Frame.cc:1135-1168)
+    void imageBounds(const PslCamera& cam, int cols, int rows, float bounds[4]) {
+        check(pslfe_image_bounds(h_, &cam, cols, rows, bounds), "pslfe_image_bounds");
+    }
     pslfe_frame* get() const { return h_; }
 private:
     pslfe_frame* h_ = nullptr;
