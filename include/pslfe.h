@@ -369,6 +369,39 @@ int pslfe_line_search_by_projection(pslfe_ctx* ctx, const PslKeyLine* kls, const
                                     float nnratio, int32_t* match, int32_t* assigned, int* nmatches, int32_t* grid_start,
                                     int32_t* grid_idx, int grid_cap, int* grid_n);
 
+/* ---- RGB-D line glue of the Frame constructor ------------------------------ */
+typedef struct pslfe_glue pslfe_glue;
+/* Buffers for up to max_batch frames of max_lines keylines and max_fans LIL rows each. */
+int pslfe_glue_create(pslfe_ctx* ctx, int max_lines, int max_fans, int max_batch, pslfe_glue** out);
+void pslfe_glue_destroy(pslfe_glue* g);
+/* == the part of Frame::ExtractLSD after the extractor (src/Frame.cc:490-660) for one frame, host pointers:
+ *    Frame::isLineGood(im, imDepth, K) :662-750 with LINEextractor::compPt3dCov / extract3dline_mahdist
+ *    (add_src/LineExtractor.cpp:40-322): per keyline <= 21 depth samples, back-projection, RANSAC 3-D line by
+ *    Mahalanobis distance -> mvLines3D, mvLineEq;
+ *    Frame::convertFansToKeyLines(fans, mvKeylinesUn) :426-472 with Frame_shortestDistance :381-424 ->
+ *    intersection_lines_plane; the plane loop :505-660 with Frame::OldPlane :474-488 -> mvPlanes, mvPlaneNormal,
+ *    mvPlaneLineNo, CrossPoint_3D, CrossPoint_2D, mvle_l.
+ *    kls: mvKeylinesUn (n); fans: the n x 4 matrix of CPartiallyRecoverConnectivity (x, y, index1, index2);
+ *    depth: CV_32F image (metres), stride in floats; cam: fx, fy, cx, cy are used.
+ *    rand() is glibc's generator seeded as srand(seed) at the start of the frame (the reference never seeds: its
+ *    stream position depends on the process history; convention H7).  Asynchronous; results via pslfe_glue_fetch. */
+int pslfe_glue_run(pslfe_glue* g, const PslKeyLine* kls, int nlines, const float* fans, int nfans, const float* depth,
+                   int width, int height, int depth_stride, const PslCamera* cam, uint32_t seed);
+/* Same for nframes frames resident in HBM: keylines [nframes][kl_stride] (kl_stride == max_lines), counts
+ * [nframes], fans [nframes][fan_stride][4], counts [nframes], depth [nframes][height][width] float; frame f is
+ * seeded with seed0 + f.  (pslfe_line_results_device / pslfe_line_pair_batch_device give exactly these views.) */
+int pslfe_glue_run_batch_device(pslfe_glue* g, int nframes, const PslKeyLine* d_kls, int kl_stride, const int32_t* d_nkl,
+                                const float* d_fans, int fan_stride, const int32_t* d_nfans, const float* d_depth,
+                                int width, int height, const PslCamera* cam, uint32_t seed0);
+/* Results of frame `frame` (any pointer may be NULL):
+ *   lines3d [nlines][6] f64 = mvLines3D (start, end; zeros when the line failed), lineEq [nlines][3] = mvLineEq
+ *   (-1,-1,-1 when failed); crossings (intersection_lines_plane, fan order): pair [k][2], xy [k][2], cross [k][3]
+ *   f64, le_l [k][6] f64 = mvle_l; planes: planes [p][4] = mvPlanes, normals [p][3] f64 = mvPlaneNormal, lineNo
+ *   [p][2] = mvPlaneLineNo, cross3d [p][3] = CrossPoint_3D, cross2d [p][2] f64 = CrossPoint_2D. */
+int pslfe_glue_fetch(pslfe_glue* g, int frame, int nlines, double* lines3d, float* lineEq, int32_t* pair, float* xy,
+                     double* cross, double* le_l, int int_cap, int* nint, float* planes, double* normals, int32_t* lineNo,
+                     double* cross3d, double* cross2d, int plane_cap, int* nplanes);
+
 #ifdef __cplusplus
 }
 #endif

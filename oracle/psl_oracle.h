@@ -105,6 +105,15 @@ void pso_image_bounds(int cols, int rows, const float* K, const float* dist, flo
 void pso_frame_post_rgbd(const PsoKeyPoint* kps, int n, const float* depth, int w, int h, int dstride, const float* K, const float* dist,
                          float mbf, PsoKeyPoint* kpsUn, float* mvDepth, float* mvuRight);
 
+/* RGB-D line glue of the Frame constructor (glue_oracle.cpp) */
+void pso_line_good(const PsoKeyLine* kls, int n, const float* depth, int cols, int rows, int dstride, const float* cam, uint32_t seed,
+                   double* lines3d, float* lineEq);
+int pso_fans_to_intersections(const float* fans, int nfans, const double* lines3d, int32_t* pair, float* xy, double* cross, int cap);
+int pso_planes_from_pairs(const PsoKeyLine* kls, const float* lineEq, const double* lines3d, const int32_t* pair, const float* xy,
+                          const double* cross, int nint, float* planes, double* normals, int32_t* lineNo, double* cross3d, double* cross2d,
+                          double* le_l, int cap);
+int pso_glibc_rand(uint32_t seed, int n, int32_t* out);
+
 #ifdef __cplusplus
 }
 #endif

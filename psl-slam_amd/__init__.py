@@ -683,3 +683,62 @@ def _lsd_search_by_projection(self, kls, desc, lineEq, bounds, queries, qdesc, m
 
 
 LSDmatcher.SearchByProjection = _lsd_search_by_projection
+
+
+class FrameGlue:
+    """== the part of Frame::ExtractLSD after the extractor (src/Frame.cc:490-660): isLineGood (3-D RANSAC per keyline),
+    convertFansToKeyLines (3-D crossing of paired lines) and the plane-from-pair loop.  `seed`: srand(seed) of the frame."""
+
+    def __init__(self, max_lines=1024, max_fans=4096, max_batch=1, ctx=None):
+        self.ctx = ctx or default_context()
+        self.max_lines, self.max_fans, self.max_batch = max_lines, max_fans, max_batch
+        self._h = C.c_void_p()
+        _check(lib().pslfe_glue_create(self.ctx._h, C.c_int(max_lines), C.c_int(max_fans), C.c_int(max_batch), C.byref(self._h)),
+               "pslfe_glue_create")
+
+    def run(self, keylines, fans, depth, cam, seed=1):
+        kls = np.ascontiguousarray(keylines, KEYLINE_DTYPE)
+        fans = np.ascontiguousarray(fans, np.float32).reshape(-1, 4)
+        depth = np.ascontiguousarray(depth, np.float32)
+        cam = np.ascontiguousarray(cam, CAMERA_DTYPE).reshape(1)
+        self._n = len(kls)
+        _check(lib().pslfe_glue_run(self._h, _ptr(kls), C.c_int(len(kls)), _ptr(fans), C.c_int(len(fans)), _ptr(depth),
+                                    C.c_int(depth.shape[1]), C.c_int(depth.shape[0]), C.c_int(depth.shape[1]), _ptr(cam),
+                                    C.c_uint32(seed)), "pslfe_glue_run")
+        return self.fetch(0, self._n)
+
+    def run_batch_device(self, nframes, d_kls, kl_stride, d_nkl, d_fans, fan_stride, d_nfans, d_depth, width, height, cam, seed0=1):
+        cam = np.ascontiguousarray(cam, CAMERA_DTYPE).reshape(1)
+        _check(lib().pslfe_glue_run_batch_device(self._h, C.c_int(nframes), C.c_void_p(int(d_kls)), C.c_int(kl_stride),
+                                                 C.c_void_p(int(d_nkl)), C.c_void_p(int(d_fans)), C.c_int(fan_stride),
+                                                 C.c_void_p(int(d_nfans)), C.c_void_p(int(d_depth)), C.c_int(width), C.c_int(height),
+                                                 _ptr(cam), C.c_uint32(seed0)), "pslfe_glue_run_batch_device")
+
+    def fetch(self, frame, nlines):
+        """dict with mvLines3D, mvLineEq, the crossings (pair, xy, cross, le_l) and the planes."""
+        I = P = self.max_fans
+        out = dict(lines3d=np.zeros((nlines, 6), np.float64), lineEq=np.zeros((nlines, 3), np.float32),
+                   pair=np.zeros((I, 2), np.int32), xy=np.zeros((I, 2), np.float32), cross=np.zeros((I, 3), np.float64),
+                   le_l=np.zeros((I, 6), np.float64), planes=np.zeros((P, 4), np.float32), normals=np.zeros((P, 3), np.float64),
+                   lineNo=np.zeros((P, 2), np.int32), cross3d=np.zeros((P, 3), np.float64), cross2d=np.zeros((P, 2), np.float64))
+        ni, npl = C.c_int(), C.c_int()
+        _check(lib().pslfe_glue_fetch(self._h, C.c_int(frame), C.c_int(nlines), _ptr(out["lines3d"]), _ptr(out["lineEq"]), _ptr(out["pair"]),
+                                      _ptr(out["xy"]), _ptr(out["cross"]), _ptr(out["le_l"]), C.c_int(I), C.byref(ni), _ptr(out["planes"]),
+                                      _ptr(out["normals"]), _ptr(out["lineNo"]), _ptr(out["cross3d"]), _ptr(out["cross2d"]), C.c_int(P),
+                                      C.byref(npl)), "pslfe_glue_fetch")
+        for k in ("pair", "xy", "cross", "le_l"):
+            out[k] = out[k][:ni.value]
+        for k in ("planes", "normals", "lineNo", "cross3d", "cross2d"):
+            out[k] = out[k][:npl.value]
+        return out
+
+    def close(self):
+        if self._h:
+            lib().pslfe_glue_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

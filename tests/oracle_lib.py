@@ -382,3 +382,37 @@ def frame_post_rgbd(kps, depth, cam):
                                       C.c_void_p, C.c_void_p, C.c_void_p]
     L.pso_frame_post_rgbd(_p(kps), n, _p(depth), depth.shape[1], depth.shape[0], depth.shape[1], _p(K), _p(dist), bf, _p(un), _p(dep), _p(ur))
     return un[:n], dep[:n], ur[:n]
+
+
+def frame_glue(keylines, fans, depth, cam, seed=1):
+    """oracle chain isLineGood -> convertFansToKeyLines -> planes, same dict as psl_slam_amd.FrameGlue.run"""
+    L = load()
+    kls = np.ascontiguousarray(keylines, KEYLINE_DTYPE)
+    fans = np.ascontiguousarray(fans, np.float32).reshape(-1, 4)
+    depth = np.ascontiguousarray(depth, np.float32)
+    K, _, _ = _cam_arrays(cam)
+    n, nf = len(kls), len(fans)
+    out = dict(lines3d=np.zeros((max(n, 1), 6), np.float64), lineEq=np.zeros((max(n, 1), 3), np.float32))
+    L.pso_line_good.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+    L.pso_line_good(_p(kls), n, _p(depth), depth.shape[1], depth.shape[0], depth.shape[1], _p(K), seed, _p(out["lines3d"]), _p(out["lineEq"]))
+    cap = max(nf, 1)
+    pair, xy, cross = np.zeros((cap, 2), np.int32), np.zeros((cap, 2), np.float32), np.zeros((cap, 3), np.float64)
+    L.pso_fans_to_intersections.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    ni = L.pso_fans_to_intersections(_p(fans), nf, _p(out["lines3d"]), _p(pair), _p(xy), _p(cross), cap)
+    planes, normals, lineNo = np.zeros((cap, 4), np.float32), np.zeros((cap, 3), np.float64), np.zeros((cap, 2), np.int32)
+    c3, c2, le_l = np.zeros((cap, 3), np.float64), np.zeros((cap, 2), np.float64), np.zeros((cap, 6), np.float64)
+    L.pso_planes_from_pairs.argtypes = [C.c_void_p] * 6 + [C.c_int] + [C.c_void_p] * 6 + [C.c_int]
+    npl = L.pso_planes_from_pairs(_p(kls), _p(out["lineEq"]), _p(out["lines3d"]), _p(pair), _p(xy), _p(cross), ni, _p(planes), _p(normals),
+                                  _p(lineNo), _p(c3), _p(c2), _p(le_l), cap)
+    out["lines3d"], out["lineEq"] = out["lines3d"][:n], out["lineEq"][:n]
+    out.update(pair=pair[:ni], xy=xy[:ni], cross=cross[:ni], le_l=le_l[:ni], planes=planes[:npl], normals=normals[:npl], lineNo=lineNo[:npl],
+               cross3d=c3[:npl], cross2d=c2[:npl])
+    return out
+
+
+def glibc_rand(seed, n):
+    L = load()
+    out = np.zeros(n, np.int32)
+    L.pso_glibc_rand.argtypes = [C.c_uint32, C.c_int, C.c_void_p]
+    L.pso_glibc_rand(seed, n, _p(out))
+    return out
