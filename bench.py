@@ -59,6 +59,8 @@ STAGE_BYTES_PER_FRAME = {
     "line.lbd": 5040000 + 20000,                       # LSR gathers + outputs
     "line.pair": 2 * 16 * 200,
     "line.match": 12800,
+    "line.good": 200 * 21 * 4 + 200 * (68 + 48 + 12),  # depth samples + keylines in, 3-D lines out
+    "line.planes": 4096 * 16 + 200 * 60,
 }
 LINE_BYTES_PER_FRAME = 17040800 + 12800
 
@@ -69,7 +71,7 @@ STAGE_KERNELS = {
     "match.grid": [("k_frame_import", 1), ("k_build_grid", 1)], "match.window": [("k_window_eval", 1), ("k_window_resolve<0, 4096, 1024>", 1)],
     "line.lsd_scale": [("k_lsd_scale_tiled", 1)], "line.lsd_grad": [("k_lsd_grad", 1)], "line.lsd_grow": [("k_lsd_grow3", 1)],
     "line.merge": [("k_line_merge", 1)], "line.lbd_pre": [("k_lbd_pre", 1)], "line.lbd": [("k_lbd", 1)], "line.pair": [("k_lil_pair", 1)],
-    "line.match": [("k_line_match_batch", 1)],
+    "line.match": [("k_line_match_batch", 1)], "line.good": [("k_line_good", 1)], "line.planes": [("k_fans_planes", 1)],
 }
 
 
@@ -222,6 +224,15 @@ def main():
         _, _, _, _, klcap = le.results_device()
         lmatch = torch.full((B, klcap), -1, dtype=torch.int32, device=dev)
         lnm = torch.zeros((B,), dtype=torch.int32, device=dev)
+        # RGB-D glue of the Frame constructor (isLineGood, convertFansToKeyLines, planes): needs the depth frames
+        import synth_frames as sf
+        dsc = sf.Scene(W, H, "struct", P_seed(rank))
+        depth_h = np.stack([dsc.depth_u16(t).astype(np.float32) / np.float32(5000.0) for t in range(16)], 0)
+        depth_d = torch.from_numpy(np.ascontiguousarray(np.concatenate([depth_h] * ((B + 15) // 16), 0)[:B])).to(dev)
+        glue = P.FrameGlue(max_lines=klcap, max_fans=4096, max_batch=B, ctx=ctx)
+        cam = np.zeros((), P.CAMERA_DTYPE)
+        for k_, v_ in zip(P.CAMERA_DTYPE.names, (517.306408, 516.469215, 318.643040, 255.313989, 0, 0, 0, 0, 0, 40.0)):
+            cam[k_] = np.float32(v_)
 
     gather = None
 
@@ -242,6 +253,9 @@ def main():
             le.extract_batch_device(frames_d.data_ptr(), B, W, H, W, W * H)   # LSD -> merge -> top-200 -> LBD -> line equations
             le.pair_batch_device(20.0, float(np.float32(np.pi / 4)))          # CPartiallyRecoverConnectivity (src/Frame.cc:505)
             le.match_batch_device(1, 0.9, lmatch.data_ptr(), lnm.data_ptr())  # lmatcher.match(last, cur, 0.9) (src/Tracking.cc:901)
+            d_kls_, _, _, d_nkl_, _ = le.results_device()
+            d_fans_, d_nfans_ = le.fans_device()
+            glue.run_batch_device(B, d_kls_, klcap, d_nkl_, d_fans_, 4096, d_nfans_, depth_d.data_ptr(), W, H, cam, 1)  # src/Frame.cc:500-660
         if gather is not None:
             gather.submit([counts, kps, desc, match, nmatches])
         return counts
@@ -255,7 +269,7 @@ def main():
         gather = multigpu.ResultGather(tmpl, world, dev)
 
     stage_names = ["orb.pyramid", "orb.fast", "orb.octree", "orb.blur", "orb.describe", "match.grid", "match.window",
-                   "line.lsd_scale", "line.lsd_grad", "line.lsd_grow", "line.merge", "line.lbd_pre", "line.lbd", "line.pair", "line.match"]
+                   "line.lsd_scale", "line.lsd_grad", "line.lsd_grow", "line.merge", "line.lbd_pre", "line.lbd", "line.pair", "line.match", "line.good", "line.planes"]
 
     def read_stages():
         out = {}

@@ -216,6 +216,8 @@ int pslfe_lil_pair(pslfe_line* line, const float* lines, int nlines, float radiu
 /* The same for every frame of the last extracted batch (mLines = keyline end points), HBM resident. */
 int pslfe_line_pair_batch_device(pslfe_line* line, float radius, float fanThr);
 int pslfe_line_fans_fetch(pslfe_line* line, int frame, float* fans, int cap, int* nfans);
+/* Device views of the fans of the last pslfe_line_pair_batch_device: [nframes][fan_stride][4] float, counts [nframes]. */
+int pslfe_line_fans_device(pslfe_line* line, const float** d_fans, const int32_t** d_nfans, int* fan_stride);
 
 /* == lmatcher.match(mLastFrame.mLdesc, mCurrentFrame.mLdesc, nnr, matches_12) of src/Tracking.cc:901
  *    (LSDmatcher::match -> matchNNR, add_src/LSDmatcher.cpp:354-413) for every frame f of the last

@@ -605,7 +605,14 @@ LINEextractor.lbd_compute = _line_lbd
 LINEextractor.debug_sobel = _line_debug_sobel
 LINEextractor.pair = _line_pair
 LINEextractor.pair_batch_device = _line_pair_batch_device
+def _line_fans_device(self):
+    f, n, st = C.c_void_p(), C.c_void_p(), C.c_int()
+    _check(lib().pslfe_line_fans_device(self._h, C.byref(f), C.byref(n), C.byref(st)), "pslfe_line_fans_device")
+    return f.value, n.value
+
+
 LINEextractor.fans_fetch = _line_fans_fetch
+LINEextractor.fans_device = _line_fans_device
 
 
 def _lsd_search_by_geom_appearance(self, kl_last, desc_last, kl_cur, desc_cur, has_mapline, desc_th, bounds):

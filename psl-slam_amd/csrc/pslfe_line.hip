@@ -482,6 +482,15 @@ int pslfe_line_pair_batch_device(pslfe_line* line, float radius, float fanThr) {
     return line->run_pair(line->last_nframes, radius, fanThr);
 }
 
+int pslfe_line_fans_device(pslfe_line* line, const float** d_fans, const int32_t** d_nfans, int* fan_stride) {
+    PSL_REQUIRE(line, PSLFE_E_INVALID, "pslfe_line_fans_device: line is NULL");
+    PSL_REQUIRE(line->last_nframes > 0, PSLFE_E_STATE, "pslfe_line_fans_device: no batch extracted yet");
+    if (d_fans) *d_fans = line->d_fans;
+    if (d_nfans) *d_nfans = line->d_nfans;
+    if (fan_stride) *fan_stride = PSL_FAN_CAP;
+    return PSLFE_OK;
+}
+
 int pslfe_line_fans_fetch(pslfe_line* line, int frame, float* fans, int cap, int* nfans) {
     PSL_REQUIRE(line && nfans, PSLFE_E_INVALID, "pslfe_line_fans_fetch: NULL argument");
     PSL_REQUIRE(line->last_nframes > 0 && frame >= 0 && frame < line->last_nframes, PSLFE_E_STATE, "pslfe_line_fans_fetch: frame %d", frame);

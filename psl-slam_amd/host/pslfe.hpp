@@ -261,5 +261,51 @@ public:
     bool mbCheckOrientation;
 };
 
+// The part of Frame::ExtractLSD after the extractor (src/Frame.cc:490-660): isLineGood, convertFansToKeyLines, planes.
+class FrameGlue {
+public:
+    struct Result {
+        std::vector<double> lines3d;   // mvLines3D, n x 6
+        std::vector<float> lineEq;     // mvLineEq, n x 3
+        std::vector<int32_t> pair;     // intersection_lines_plane: line indices, k x 2
+        std::vector<float> xy;         // ... 2-D crossing, k x 2
+        std::vector<double> cross;     // ... 3-D crossing, k x 3
+        std::vector<double> le_l;      // mvle_l, k x 6
+        std::vector<float> planes;     // mvPlanes, p x 4
+        std::vector<double> normals;   // mvPlaneNormal, p x 3
+        std::vector<int32_t> lineNo;   // mvPlaneLineNo, p x 2
+        std::vector<double> cross3d;   // CrossPoint_3D, p x 3
+        std::vector<double> cross2d;   // CrossPoint_2D, p x 2
+    };
+    FrameGlue(Context& ctx, int maxLines = 1024, int maxFans = 4096) : maxFans_(maxFans) {
+        check(pslfe_glue_create(ctx.get(), maxLines, maxFans, 1, &h_), "pslfe_glue_create");
+    }
+    ~FrameGlue() { pslfe_glue_destroy(h_); }
+    FrameGlue(const FrameGlue&) = delete;
+    FrameGlue& operator=(const FrameGlue&) = delete;
+    // fans: the n x 4 matrix of CPartiallyRecoverConnectivity; seed: srand(seed) of the frame (convention H7)
+    Result run(const std::vector<PslKeyLine>& keylines, const std::vector<float>& fans, const float* depth, int cols, int rows, int strideFloats,
+               const PslCamera& cam, uint32_t seed) {
+        const int n = (int)keylines.size(), nf = (int)fans.size() / 4, cap = maxFans_;
+        check(pslfe_glue_run(h_, keylines.data(), n, fans.data(), nf, depth, cols, rows, strideFloats, &cam, seed), "pslfe_glue_run");
+        Result r;
+        r.lines3d.resize((size_t)n * 6); r.lineEq.resize((size_t)n * 3);
+        r.pair.resize((size_t)cap * 2); r.xy.resize((size_t)cap * 2); r.cross.resize((size_t)cap * 3); r.le_l.resize((size_t)cap * 6);
+        r.planes.resize((size_t)cap * 4); r.normals.resize((size_t)cap * 3); r.lineNo.resize((size_t)cap * 2);
+        r.cross3d.resize((size_t)cap * 3); r.cross2d.resize((size_t)cap * 2);
+        int k = 0, p = 0;
+        check(pslfe_glue_fetch(h_, 0, n, r.lines3d.data(), r.lineEq.data(), r.pair.data(), r.xy.data(), r.cross.data(), r.le_l.data(), cap, &k,
+                               r.planes.data(), r.normals.data(), r.lineNo.data(), r.cross3d.data(), r.cross2d.data(), cap, &p),
+              "pslfe_glue_fetch");
+        r.pair.resize((size_t)k * 2); r.xy.resize((size_t)k * 2); r.cross.resize((size_t)k * 3); r.le_l.resize((size_t)k * 6);
+        r.planes.resize((size_t)p * 4); r.normals.resize((size_t)p * 3); r.lineNo.resize((size_t)p * 2);
+        r.cross3d.resize((size_t)p * 3); r.cross2d.resize((size_t)p * 2);
+        return r;
+    }
+private:
+    pslfe_glue* h_ = nullptr;
+    int maxFans_;
+};
+
 }  // namespace pslfe
 #endif
