@@ -116,7 +116,7 @@ def bench_kernels():
     return lib
 
 
-def cpu_baseline(sample_frames, lines=False):
+def cpu_baseline(sample_frames, lines=False, depth_frames=None, cam=None):
     """Oracle (CPU restatement) timed single-threaded on the same workload: extract + match."""
     import ctypes as C
     import oracle_lib
@@ -147,7 +147,9 @@ def cpu_baseline(sample_frames, lines=False):
         if lines:
             kls, ldesc, _ = oracle_lib.line_extract(img, 200)
             L4 = np.stack([kls[k] for k in ("startPointX", "startPointY", "endPointX", "endPointY")], 1).astype(np.float32) if len(kls) else np.zeros((0, 4), np.float32)
-            oracle_lib.lil_pair(L4, 20.0, np.float32(np.pi / 4), W, H)
+            fans = oracle_lib.lil_pair(L4, 20.0, np.float32(np.pi / 4), W, H)
+            if depth_frames is not None:  # isLineGood + convertFansToKeyLines + planes (src/Frame.cc:500-660)
+                oracle_lib.frame_glue(kls, fans, depth_frames[n % len(depth_frames)], cam, seed=1 + n)
             if prev is not None and len(prev) > 2:
                 oracle_lib.line_match_nnr(prev[2], ldesc, 0.9)
             prev = (kps, desc, ldesc)
@@ -157,7 +159,7 @@ def cpu_baseline(sample_frames, lines=False):
         if time.perf_counter() - t0 > 20.0:
             break
     dt = time.perf_counter() - t0
-    what = ("ORB 1000 + LSD/merge/LBD 200 + LIL pairing extract, SearchByProjection(cur,last) + matchNNR" if lines
+    what = ("ORB 1000 + LSD/merge/LBD 200 + LIL pairing + RGB-D line glue extract, SearchByProjection(cur,last) + matchNNR" if lines
             else "ORB 1000 extract + SearchByProjection(cur,last)")
     return {"value": round(n / dt, 2), "unit": "frames/s", "cores": 1, "kind": "port",
             "sample": f"{n} frames 640x480 synthetic stream, {what}, "
@@ -333,7 +335,8 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": ("configs[2]: 640x480 synthetic structure-notexture-like stream, ORB 1000/1.2/8 FAST 20/7 + LSD/merge/LBD 200 lines "
-                                    "+ LIL pairing extract, SearchByProjection(cur,last) + LSDmatcher::match, frames resident in HBM") if LINES else
+                                    "+ LIL pairing + RGB-D line glue (isLineGood, crossings, planes) extract, SearchByProjection(cur,last) + LSDmatcher::match, "
+                                    "frames resident in HBM") if LINES else
                                    ("configs[1]: 640x480 synthetic RGB-D stream (desk-like), ORB 1000/1.2/8 FAST 20/7 "
                                     "extract + SearchByProjection(cur,last) match, frames resident in HBM"),
                        "frames_per_step_per_gpu": B, "mean_keypoints": round(mean_kp, 1), "mean_matches": round(mean_matches, 1),
@@ -347,7 +350,8 @@ def main():
             "stages_ms_per_launch": {k: round(v["ms_per_launch"], 4) for k, v in stages.items()},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(frames_h, lines=LINES)  # stops after ~25 s of CPU work
+            out["cpu_baseline"] = cpu_baseline(frames_h, lines=LINES, depth_frames=depth_h if LINES else None,
+                                               cam=cam if LINES else None)  # stops after ~25 s of CPU work
         if LINES:
             out["config"]["mean_line_matches"] = round(float(lnm.float().mean().item()), 1)
         print(json.dumps(out), flush=True)

@@ -28,74 +28,98 @@ __device__ __forceinline__ GlueP3 operator*(const GlueP3& a, double s) { return 
 __device__ __forceinline__ double gdot(const GlueP3& a, const GlueP3& b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 __device__ __forceinline__ double gnorm(const GlueP3& a) { return __dsqrt_rn(a.x * a.x + a.y * a.y + a.z * a.z); }
 
-// OpenCV JacobiSVDImpl_<double> on n rows of length m; ROWLEN = row pitch of At.  Rows of At come back normalised,
-// W descending, Vt = accumulated rotations (n x n).
-template <int ROWLEN>
-__device__ void psl_jacobi_rows(double* At, double* W, double* Vt, int m, int n) {
+// OpenCV JacobiSVDImpl_<double> on N rows of length M held by one lane (compile-time sizes: everything stays in
+// registers).  Rows of At come back normalised, W descending, Vt = accumulated rotations (N x N).
+template <int M, int N>
+__device__ __forceinline__ void psl_jacobi_rows(double (&At)[N][M], double (&W)[N], double (&Vt)[N][N]) {
     const double eps = 2.220446049250313e-16 * 10;
-    const int max_iter = m > 30 ? m : 30;
-    double Wd[3];
-    for (int i = 0; i < n; ++i) {
+    const int max_iter = M > 30 ? M : 30;
+    double Wd[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
         double sd = 0;
-        for (int k = 0; k < m; ++k) sd += At[i * ROWLEN + k] * At[i * ROWLEN + k];
+#pragma unroll
+        for (int k = 0; k < M; ++k) sd += At[i][k] * At[i][k];
         Wd[i] = sd;
-        for (int k = 0; k < n; ++k) Vt[i * 3 + k] = 0;
-        Vt[i * 3 + i] = 1;
+#pragma unroll
+        for (int k = 0; k < N; ++k) Vt[i][k] = 0;
+        Vt[i][i] = 1;
     }
     for (int iter = 0; iter < max_iter; ++iter) {
         bool changed = false;
-        for (int i = 0; i < n - 1; ++i)
-            for (int j = i + 1; j < n; ++j) {
+#pragma unroll
+        for (int i = 0; i < N - 1; ++i)
+#pragma unroll
+            for (int j = i + 1; j < N; ++j) {
                 double a = Wd[i], p = 0, b = Wd[j];
-                for (int k = 0; k < m; ++k) p += At[i * ROWLEN + k] * At[j * ROWLEN + k];
-                if (fabs(p) <= eps * __dsqrt_rn(a * b)) continue;
-                p *= 2;
-                const double beta = a - b, gamma = __dsqrt_rn(p * p + beta * beta);
-                double c, s;
-                if (beta < 0) {
-                    const double delta = (gamma - beta) * 0.5;
-                    s = __dsqrt_rn(delta / gamma);
-                    c = p / (gamma * s * 2);
-                } else {
-                    c = __dsqrt_rn((gamma + beta) / (gamma * 2));
-                    s = p / (gamma * c * 2);
-                }
-                a = b = 0;
-                for (int k = 0; k < m; ++k) {
-                    const double t0 = c * At[i * ROWLEN + k] + s * At[j * ROWLEN + k];
-                    const double t1 = -s * At[i * ROWLEN + k] + c * At[j * ROWLEN + k];
-                    At[i * ROWLEN + k] = t0; At[j * ROWLEN + k] = t1;
-                    a += t0 * t0; b += t1 * t1;
-                }
-                Wd[i] = a; Wd[j] = b;
-                changed = true;
-                for (int k = 0; k < n; ++k) {
-                    const double t0 = c * Vt[i * 3 + k] + s * Vt[j * 3 + k];
-                    const double t1 = -s * Vt[i * 3 + k] + c * Vt[j * 3 + k];
-                    Vt[i * 3 + k] = t0; Vt[j * 3 + k] = t1;
+#pragma unroll
+                for (int k = 0; k < M; ++k) p += At[i][k] * At[j][k];
+                if (!(fabs(p) <= eps * __dsqrt_rn(a * b))) {
+                    p *= 2;
+                    const double beta = a - b, gamma = __dsqrt_rn(p * p + beta * beta);
+                    double c, s;
+                    if (beta < 0) {
+                        const double delta = (gamma - beta) * 0.5;
+                        s = __dsqrt_rn(delta / gamma);
+                        c = p / (gamma * s * 2);
+                    } else {
+                        c = __dsqrt_rn((gamma + beta) / (gamma * 2));
+                        s = p / (gamma * c * 2);
+                    }
+                    a = b = 0;
+#pragma unroll
+                    for (int k = 0; k < M; ++k) {
+                        const double t0 = c * At[i][k] + s * At[j][k];
+                        const double t1 = -s * At[i][k] + c * At[j][k];
+                        At[i][k] = t0; At[j][k] = t1;
+                        a += t0 * t0; b += t1 * t1;
+                    }
+                    Wd[i] = a; Wd[j] = b;
+                    changed = true;
+#pragma unroll
+                    for (int k = 0; k < N; ++k) {
+                        const double t0 = c * Vt[i][k] + s * Vt[j][k];
+                        const double t1 = -s * Vt[i][k] + c * Vt[j][k];
+                        Vt[i][k] = t0; Vt[j][k] = t1;
+                    }
                 }
             }
         if (!changed) break;
     }
-    for (int i = 0; i < n; ++i) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
         double sd = 0;
-        for (int k = 0; k < m; ++k) sd += At[i * ROWLEN + k] * At[i * ROWLEN + k];
+#pragma unroll
+        for (int k = 0; k < M; ++k) sd += At[i][k] * At[i][k];
         Wd[i] = __dsqrt_rn(sd);
     }
-    for (int i = 0; i < n - 1; ++i) {
-        int j = i;
-        for (int k = i + 1; k < n; ++k)
-            if (Wd[j] < Wd[k]) j = k;
-        if (i != j) {
-            const double t = Wd[i]; Wd[i] = Wd[j]; Wd[j] = t;
-            for (int k = 0; k < m; ++k) { const double u = At[i * ROWLEN + k]; At[i * ROWLEN + k] = At[j * ROWLEN + k]; At[j * ROWLEN + k] = u; }
-            for (int k = 0; k < n; ++k) { const double u = Vt[i * 3 + k]; Vt[i * 3 + k] = Vt[j * 3 + k]; Vt[j * 3 + k] = u; }
+#pragma unroll
+    for (int i = 0; i < N - 1; ++i) {
+        // selection of the largest remaining value (first one on ties), then a swap: written without dynamic indices
+        int j = i;  // "if (Wd[j] < Wd[k]) j = k" followed by one swap(i, j), without dynamic indices
+#pragma unroll
+        for (int k = i + 1; k < N; ++k) {
+            double wj = Wd[i];
+#pragma unroll
+            for (int q = i + 1; q < N; ++q) wj = (j == q) ? Wd[q] : wj;
+            if (wj < Wd[k]) j = k;
         }
+#pragma unroll
+        for (int q = i + 1; q < N; ++q)
+            if (j == q) {
+                const double t = Wd[i]; Wd[i] = Wd[q]; Wd[q] = t;
+#pragma unroll
+                for (int k = 0; k < M; ++k) { const double u = At[i][k]; At[i][k] = At[q][k]; At[q][k] = u; }
+#pragma unroll
+                for (int k = 0; k < N; ++k) { const double u = Vt[i][k]; Vt[i][k] = Vt[q][k]; Vt[q][k] = u; }
+            }
     }
-    for (int i = 0; i < n; ++i) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
         W[i] = Wd[i];
         const double s = Wd[i] > 2.2250738585072014e-308 ? 1 / Wd[i] : 0.;
-        for (int k = 0; k < m; ++k) At[i * ROWLEN + k] *= s;
+#pragma unroll
+        for (int k = 0; k < M; ++k) At[i][k] *= s;
     }
 }
 
@@ -114,15 +138,17 @@ __device__ void psl_comp_du(const GlueP3& pt, double f, double* DU) {
     for (int i = 0; i < 3; ++i)
 #pragma unroll
         for (int j = 0; j < 3; ++j) cov[i][j] = JG[i][0] * J0[j][0] + JG[i][1] * J0[j][1] + JG[i][2] * J0[j][2];
-    double At[9], W[3], Vt[9];
+    double At[3][3], W[3], Vt[3][3];
 #pragma unroll
     for (int i = 0; i < 3; ++i)
 #pragma unroll
-        for (int j = 0; j < 3; ++j) At[i * 3 + j] = cov[j][i];
-    psl_jacobi_rows<3>(At, W, Vt, 3, 3);
+        for (int j = 0; j < 3; ++j) At[i][j] = cov[j][i];
+    psl_jacobi_rows<3, 3>(At, W, Vt);
+#pragma unroll
     for (int r = 0; r < 3; ++r) {
         const double d = 1 / __dsqrt_rn(W[r]);
-        for (int c = 0; c < 3; ++c) DU[3 * r + c] = d * At[r * 3 + c];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) DU[3 * r + c] = d * At[r][c];
     }
 }
 
@@ -170,10 +196,9 @@ __device__ int psl_first_arg(double v, unsigned long long mask, bool want_min) {
 struct GlueLds {
     double pos[PSL_GLUE_MAXPTS][3];
     double DU[PSL_GLUE_MAXPTS][9];
-    double At[3 * 32];
-    double svd_out[6];  // tmp_m, tmp_d
     uint32_t ring[34];
-    int idx[PSL_GLUE_MAXPTS + 3];
+    int idx[PSL_GLUE_MAXPTS + 3];   // the RANSAC shuffle (`indexes`)
+    int rank[PSL_GLUE_MAXPTS + 3];  // rank -> point of an inlier set
 };
 
 __device__ __forceinline__ GlueP3 glue_pos(const GlueLds& S, int i) { return {S.pos[i][0], S.pos[i][1], S.pos[i][2]}; }
@@ -200,36 +225,117 @@ __device__ bool psl_verify_line(const GlueLds& S, unsigned long long mask, const
     return sum / 10 > 0.7;
 }
 
-// computeLine3d_svd (:163-185) on the points of `mask`; lane 0 computes, result in S.svd_out
-__device__ void psl_line_svd(GlueLds& S, unsigned long long mask) {
-    if ((threadIdx.x & 63) == 0) {
-        const int n = __popcll(mask);
-        GlueP3 mean = {0, 0, 0};
-        for (unsigned long long mm = mask; mm; mm &= mm - 1) mean = mean + glue_pos(S, (int)__ffsll((long long)mm) - 1);
-        mean = mean * (1.0 / n);
-        double W[3], Vt[9];
-        GlueP3 drct;
-        if (n >= 3) {  // cv::SVD(P.t()), P.t() n x 3: A^T has 3 rows of length n, vt = V^T
-            int c = 0;
-            for (unsigned long long mm = mask; mm; mm &= mm - 1, ++c) {
-                const GlueP3 p = glue_pos(S, (int)__ffsll((long long)mm) - 1);
-                S.At[c] = p.x - mean.x; S.At[32 + c] = p.y - mean.y; S.At[64 + c] = p.z - mean.z;
-            }
-            psl_jacobi_rows<32>(S.At, W, Vt, n, 3);
-            drct = {Vt[0], Vt[1], Vt[2]};
-        } else {       // fewer rows than columns: the rows of P.t() themselves, vt = their normalised rotations
-            int c = 0;
-            for (unsigned long long mm = mask; mm; mm &= mm - 1, ++c) {
-                const GlueP3 p = glue_pos(S, (int)__ffsll((long long)mm) - 1);
-                S.At[32 * c] = p.x - mean.x; S.At[32 * c + 1] = p.y - mean.y; S.At[32 * c + 2] = p.z - mean.z;
-            }
-            psl_jacobi_rows<32>(S.At, W, Vt, 3, n);
-            drct = {S.At[0], S.At[1], S.At[2]};
-        }
-        S.svd_out[0] = mean.x; S.svd_out[1] = mean.y; S.svd_out[2] = mean.z;
-        S.svd_out[3] = drct.x; S.svd_out[4] = drct.y; S.svd_out[5] = drct.z;
+// Sum of `term` over lanes 0..m-1 in lane order (the reference's sequential accumulation), the same value in every lane.
+__device__ __forceinline__ double psl_ordered_sum(double term, int m) {
+    double s = 0;
+    for (int k = 0; k < m; ++k) {
+        const int lo = __builtin_amdgcn_readlane(__double2loint(term), k), hi = __builtin_amdgcn_readlane(__double2hiint(term), k);
+        s += __hiloint2double(hi, lo);
     }
+    return s;
+}
+
+// psl_jacobi_rows with the matrix spread over the wave: lane k holds column k of the n (<= 3) rows, a[i] = At[i][k]
+// (0 in lanes >= m).  Products and rotations run in parallel over the columns; every sum is formed in column order, so
+// the result equals the sequential loop bit for bit.  W, Vt are uniform.
+__device__ void psl_jacobi_wave(double a[3], int m, int n, double W[3], double Vt[9]) {
+    const double eps = 2.220446049250313e-16 * 10;
+    const int max_iter = m > 30 ? m : 30;
+    double Wd[3] = {0, 0, 0};
+    for (int i = 0; i < n; ++i) {
+        Wd[i] = psl_ordered_sum(a[i] * a[i], m);
+        for (int k = 0; k < n; ++k) Vt[i * 3 + k] = 0;
+        Vt[i * 3 + i] = 1;
+    }
+    for (int iter = 0; iter < max_iter; ++iter) {
+        bool changed = false;
+        for (int i = 0; i < n - 1; ++i)
+            for (int j = i + 1; j < n; ++j) {
+                double aa = Wd[i], bb = Wd[j];
+                double p = psl_ordered_sum(a[i] * a[j], m);
+                if (fabs(p) <= eps * __dsqrt_rn(aa * bb)) continue;
+                p *= 2;
+                const double beta = aa - bb, gamma = __dsqrt_rn(p * p + beta * beta);
+                double c, sn;
+                if (beta < 0) {
+                    const double delta = (gamma - beta) * 0.5;
+                    sn = __dsqrt_rn(delta / gamma);
+                    c = p / (gamma * sn * 2);
+                } else {
+                    c = __dsqrt_rn((gamma + beta) / (gamma * 2));
+                    sn = p / (gamma * c * 2);
+                }
+                const double t0 = c * a[i] + sn * a[j];
+                const double t1 = -sn * a[i] + c * a[j];
+                a[i] = t0; a[j] = t1;
+                Wd[i] = psl_ordered_sum(t0 * t0, m);
+                Wd[j] = psl_ordered_sum(t1 * t1, m);
+                changed = true;
+                for (int k = 0; k < n; ++k) {
+                    const double v0 = c * Vt[i * 3 + k] + sn * Vt[j * 3 + k];
+                    const double v1 = -sn * Vt[i * 3 + k] + c * Vt[j * 3 + k];
+                    Vt[i * 3 + k] = v0; Vt[j * 3 + k] = v1;
+                }
+            }
+        if (!changed) break;
+    }
+    for (int i = 0; i < n; ++i) Wd[i] = __dsqrt_rn(psl_ordered_sum(a[i] * a[i], m));
+    for (int i = 0; i < n - 1; ++i) {
+        int j = i;
+        for (int k = i + 1; k < n; ++k)
+            if (Wd[j] < Wd[k]) j = k;
+        if (i != j) {
+            const double t = Wd[i]; Wd[i] = Wd[j]; Wd[j] = t;
+            const double u = a[i]; a[i] = a[j]; a[j] = u;
+            for (int k = 0; k < n; ++k) { const double v = Vt[i * 3 + k]; Vt[i * 3 + k] = Vt[j * 3 + k]; Vt[j * 3 + k] = v; }
+        }
+    }
+    for (int i = 0; i < n; ++i) {
+        W[i] = Wd[i];
+        const double sc = Wd[i] > 2.2250738585072014e-308 ? 1 / Wd[i] : 0.;
+        a[i] *= sc;
+    }
+}
+
+// computeLine3d_svd (:163-185) on the points of `mask` (lane = point index); returns mean and direction in every lane
+__device__ void psl_line_svd(GlueLds& S, unsigned long long mask, const GlueP3& me, GlueP3* mean_out, GlueP3* drct_out) {
+    const int lane = threadIdx.x & 63;
+    const int n = __popcll(mask);
+    GlueP3 mean = {0, 0, 0};
+    for (unsigned long long mm = mask; mm; mm &= mm - 1) {  // mean = mean + pts[idx[i]].pos, in index order
+        const int L = (int)__ffsll((long long)mm) - 1;
+        mean = mean + glue_pos(S, L);
+    }
+    mean = mean * (1.0 / n);
+    // rank r of an inlier = its column / row in the matrix
+    if ((mask >> lane) & 1ull) S.rank[__popcll(mask & ((1ull << lane) - 1ull))] = lane;
     __builtin_amdgcn_wave_barrier();
+    double W[3], Vt[9], a[3] = {0, 0, 0};
+    GlueP3 drct;
+    if (n >= 3) {  // cv::SVD(P.t()), P.t() n x 3: A^T has 3 rows of length n, vt = V^T
+        if (lane < n) {
+            const GlueP3 p = glue_pos(S, S.rank[lane]);
+            a[0] = p.x - mean.x; a[1] = p.y - mean.y; a[2] = p.z - mean.z;
+        }
+        psl_jacobi_wave(a, n, 3, W, Vt);
+        drct = {Vt[0], Vt[1], Vt[2]};
+    } else {       // fewer rows than columns: the rows of P.t() themselves (n rows of length 3), vt = their normalised rotations
+        if (lane < 3) {
+            for (int r = 0; r < n; ++r) {
+                const GlueP3 p = glue_pos(S, S.rank[r]);
+                a[r] = lane == 0 ? p.x - mean.x : (lane == 1 ? p.y - mean.y : p.z - mean.z);
+            }
+        }
+        psl_jacobi_wave(a, 3, n, W, Vt);
+        const double r0 = a[0];
+        drct.x = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(r0), 0), __builtin_amdgcn_readlane(__double2loint(r0), 0));
+        drct.y = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(r0), 1), __builtin_amdgcn_readlane(__double2loint(r0), 1));
+        drct.z = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(r0), 2), __builtin_amdgcn_readlane(__double2loint(r0), 2));
+    }
+    __builtin_amdgcn_wave_barrier();  // S.rank is rewritten by the next call
+    (void)me;
+    *mean_out = mean;
+    *drct_out = drct;
 }
 
 // glibc rand(): TYPE_3 ring in LDS, advanced by lane 0; *k is the (uniform) stream position
@@ -256,7 +362,7 @@ __device__ __forceinline__ int psl_glibc_rand_lane0(GlueLds& S, int k) {  // lan
     return (int)(v >> 1);
 }
 
-__global__ __launch_bounds__(64) void k_line_good(const PslKeyLine* __restrict__ kls, int kl_stride, const int32_t* __restrict__ nkl,
+__global__ __launch_bounds__(64, 4) void k_line_good(const PslKeyLine* __restrict__ kls, int kl_stride, const int32_t* __restrict__ nkl,
                                                    int nkl_single, const float* __restrict__ depth, int cols, int rows, int dstride,
                                                    size_t dframe, PslCamera cam, uint32_t seed0, double* __restrict__ lines3d,
                                                    float* __restrict__ lineEq) {
@@ -356,11 +462,10 @@ __global__ __launch_bounds__(64) void k_line_good(const PslKeyLine* __restrict__
         if (maxCnt >= 2) {
             GlueP3 m = (glue_pos(S, bestA) + glue_pos(S, bestB)) * 0.5, d = glue_pos(S, bestB) - glue_pos(S, bestA);
             while (true) {
-                psl_line_svd(S, maxMask);
-                const GlueP3 tm = {S.svd_out[0], S.svd_out[1], S.svd_out[2]}, td = {S.svd_out[3], S.svd_out[4], S.svd_out[5]};
+                GlueP3 tm, td;
+                psl_line_svd(S, maxMask, me, &tm, &td);
                 const bool in = lane < np && psl_mah_dist(myDU, me, tm, tm + td) < distThresh;
                 const unsigned long long tmask = __ballot(in);
-                __builtin_amdgcn_wave_barrier();  // svd_out is rewritten by the next round
                 if (__popcll(tmask) > maxCnt) { maxMask = tmask; maxCnt = __popcll(tmask); m = tm; d = td; }
                 else break;
             }

@@ -63,6 +63,22 @@ def lines():
     print("lines", len(seg), len(kls), len(fans))
 
 
+def glue():
+    import glue_scene
+    kls, fans, depth, cam, _ = glue_scene.scene(seed=3)
+    r = oracle_lib.frame_glue(kls, fans, depth, cam, seed=1)
+    # the depth image is re-rendered by glue_scene (1.2 MB as f32); its CRC pins it
+    import zlib
+    np.savez_compressed(os.path.join(HERE, "glue_640x480_corner.npz"), kls=kls, fans=fans, depth_crc=np.uint32(zlib.crc32(depth.tobytes())),
+                        seed=np.uint32(1), **{"out_" + k: v for k, v in r.items()})
+    print("glue", int((np.abs(r["lines3d"]).sum(1) > 0).sum()), len(r["pair"]), len(r["planes"]))
+
+
 if __name__ == "__main__":
-    lines()
-    main()
+    which = sys.argv[1:] or ["lines", "main", "glue"]
+    if "lines" in which:
+        lines()
+    if "main" in which:
+        main()
+    if "glue" in which:
+        glue()

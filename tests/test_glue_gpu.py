@@ -79,3 +79,13 @@ def test_frame_glue_batch_device():
     ctx.synchronize()
     for p in (d_kls, d_fans, d_nkl, d_nfans, d_depth):
         ctx.device_free(p)
+
+
+def test_hip_vs_committed_glue_golden():
+    import os
+    import psl_slam_amd as P
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "glue_640x480_corner.npz"))
+    _, _, depth, cam, _ = glue_scene.scene(seed=3)
+    got = P.FrameGlue(max_lines=256, max_fans=512).run(g["kls"], g["fans"], depth, cam, seed=int(g["seed"]))
+    for k in KEYS:
+        assert got[k].tobytes() == g["out_" + k].tobytes(), k

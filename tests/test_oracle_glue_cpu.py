@@ -88,3 +88,16 @@ def test_seed_changes_the_ransac_stream_but_not_the_contract():
     assert not np.array_equal(a["lines3d"], c["lines3d"])  # different samples, different end points somewhere
     ga, gc = np.abs(a["lines3d"]).sum(1) > 0, np.abs(c["lines3d"]).sum(1) > 0
     assert (ga == gc).mean() > 0.9
+
+
+def test_glue_golden_vectors():
+    """The committed fixture (tests/golden/glue_640x480_corner.npz, made by make_golden.py from the oracle) still holds."""
+    import os
+    import zlib
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "glue_640x480_corner.npz"))
+    kls, fans, depth, cam, _ = glue_scene.scene(seed=3)
+    assert zlib.crc32(depth.tobytes()) == int(g["depth_crc"])
+    assert kls.tobytes() == g["kls"].tobytes() and fans.tobytes() == g["fans"].tobytes()
+    r = oracle_lib.frame_glue(kls, fans, depth, cam, seed=int(g["seed"]))
+    for k, v in r.items():
+        assert v.tobytes() == g["out_" + k].tobytes(), k
