@@ -264,3 +264,19 @@ def test_hip_vs_committed_line_golden():
     E = np.stack([k[n] for n in ("startPointX", "startPointY", "endPointX", "endPointY")], 1)
     R = np.stack([g["kls"][n] for n in ("startPointX", "startPointY", "endPointX", "endPointY")], 1)
     assert np.abs(E - R).max() <= 0.5
+
+
+def test_line_extractor_xcd_grid_ragged_batch():
+    """9 frames: the XCD-aware grids of the scale / LBD pre-pass kernels with a ragged last group; every frame equals the
+    single-frame path (which uses the plain grids and is checked against the oracle above)."""
+    import psl_slam_amd as P
+    frames = np.stack([_scene("struct", 5, t) for t in range(9)], 0)
+    le = P.LINEextractor(1, 1.2, 200, 0.0, max_batch=9)
+    d_ptr, _ = le.ctx.device_array(frames)
+    le.extract_batch_device(d_ptr, 9, 640, 480, 640, 640 * 480)
+    single = P.LINEextractor(1, 1.2, 200, 0.0)
+    for f in range(9):
+        k, dsc, eq, st = le.fetch(f)
+        k1, d1, e1 = single(frames[f])
+        assert st == 0 and k.tobytes() == k1.tobytes() and (dsc == d1).all() and eq.tobytes() == e1.tobytes(), f"frame {f}"
+    le.ctx.device_free(d_ptr)

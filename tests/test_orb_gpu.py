@@ -148,3 +148,13 @@ def test_full_size_batch_properties():
         kb, db = res[f % 8]
         assert k.tobytes() == kb.tobytes() and (d == db).all(), f"frame {f} differs from its twin {f % 8}"
         assert 0 < len(k) <= cap and (np.diff(k["octave"]) >= 0).all()
+
+
+def test_xcd_grid_with_a_ragged_last_group():
+    """11 frames: the many-frames launches use the XCD-aware grid (8, items, ceil(F / 8)), whose last group holds 3
+    frames and 5 idle XCD slots; every frame must still equal the oracle."""
+    frames = sf.stream(11, 640, 480, "desk", seed=9)
+    gpu, orc = _pair(max_batch=11)
+    res = gpu.extract_batch(frames)
+    for f in range(11):
+        _assert_same_frame(res[f], orc(frames[f]), f"xcd batch frame {f}")
