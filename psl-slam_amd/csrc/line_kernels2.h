@@ -101,17 +101,51 @@ __device__ void psl_merge_two_lines(const float* l1, const float* l2, float* out
 
 // One MergeLines pass (src[0..n) -> M.merged) followed by FilterShortLines(length_thr) into dst.
 // Called by all 256 threads; returns the new count (uniform).  s_i[1] accumulates the overflow flag.
-__device__ int psl_merge_pass(const MergeScratch& M, const float* src, float* dst, int n, float angle_threshold, float distance_threshold,
-                              float endpoint_threshold, float length_thr, int* s_i) {
+// The clustering below is the reference's serial algorithm, run by one thread; with its working set in HBM every step
+// is a dependent ~1 us access (85 % of the kernel's wave time was s_waitcnt).  For n <= PSL_MERGE_LDSN (always, at
+// 640x480) the per-line arrays it chases live in LDS: cluster code, sort order / position, length, the two BFS
+// frontiers, the sub-cluster marks.  Larger inputs use the HBM arrays (same code through flat pointers).
+#define PSL_MERGE_LDSN 1024
+__device__ __forceinline__ int psl_block_excl_scan256(int v, int* s_w, int* total);
+struct MergeLds {
+    int code[PSL_MERGE_LDSN], order[PSL_MERGE_LDSN], pos[PSL_MERGE_LDSN], tc[PSL_MERGE_LDSN], nx[PSL_MERGE_LDSN], loc[PSL_MERGE_LDSN];
+    float length[PSL_MERGE_LDSN];
+    uint32_t bits[PSL_MERGE_LDSN / 32];
+    uint8_t clustered[PSL_MERGE_LDSN];
+    __attribute__((aligned(16))) uint32_t row[PSL_MERGE_NMAX / 32];  // the adjacency row being scanned by the serial clustering
+};
+
+// One adjacency row HBM -> LDS with the 16-byte loads of up to 8 quads in flight: the serial scan below would otherwise
+// pay one dependent round trip per 32-pair word.
+__device__ __forceinline__ const uint32_t* psl_merge_row(MergeLds& LD, const uint32_t* row, int words) {
+    const uint4* r4 = reinterpret_cast<const uint4*>(row);
+    uint4* d4 = reinterpret_cast<uint4*>(LD.row);
+    const int nq = (words + 3) >> 2;
+    for (int base = 0; base < nq; base += 8) {
+        uint4 t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = base + u < nq ? r4[base + u] : make_uint4(0, 0, 0, 0);
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (base + u < nq) d4[base + u] = t[u];
+    }
+    return LD.row;
+}
+
+__device__ int psl_merge_pass(const MergeScratch& M, MergeLds& LD, const float* src, float* dst, int n, float angle_threshold,
+                              float distance_threshold, float endpoint_threshold, float length_thr, int* s_i) {
     const int tid = threadIdx.x, BS = 256;
     if (n <= 0) return 0;
+    const bool small = n <= PSL_MERGE_LDSN;
     const int words = (n + 31) >> 5;
     const int ROW = PSL_MERGE_NMAX / 32;
     for (int i = tid; i < n; i += BS) {
         const float dx = PSL_FSUB(src[4 * i + 2], src[4 * i]), dy = PSL_FSUB(src[4 * i + 3], src[4 * i + 1]);
         M.angles[i] = atanf(PSL_FDIV(dy, dx));  // Eigen ArrayXf::atan()
-        M.length[i] = sqrtf(PSL_FADD(PSL_FMUL(dx, dx), PSL_FMUL(dy, dy)));
+        const float len = sqrtf(PSL_FADD(PSL_FMUL(dx, dx), PSL_FMUL(dy, dy)));
+        M.length[i] = len;
         M.code[i] = -1;
+        if (small) { LD.length[i] = len; LD.code[i] = -1; }
     }
     __syncthreads();
     for (int i = tid; i < n; i += BS) {  // std::sort of indices by angle (stable convention H16): rank by counting
@@ -120,62 +154,228 @@ __device__ int psl_merge_pass(const MergeScratch& M, const float* src, float* ds
         for (int j = 0; j < n; ++j) { const float b = M.angles[j]; r += (b < a) || (b == a && j < i); }
         M.pos[i] = r;
         M.order[r] = i;
+        if (small) { LD.pos[i] = r; LD.order[r] = i; }
     }
     __syncthreads();
     const float ep_thr = PSL_FMUL(endpoint_threshold, endpoint_threshold);
-    for (int t = tid; t < n * words; t += BS) {  // adjacency over sorted positions, one 32-pair word per step
-        const int pi = t / words, wj = t - pi * words;
-        uint32_t bw = 0;
-        const int idxi = M.order[pi];
-        for (int b = 0; b < 32; ++b) {
-            const int pj = wj * 32 + b;
-            if (pj >= n || pj == pi) continue;
-            const int idxj = M.order[pj];
-            const bool m = pi < pj ? psl_merge_pair(src, M.angles, idxi, idxj, angle_threshold, distance_threshold, ep_thr)
-                                   : psl_merge_pair(src, M.angles, idxj, idxi, angle_threshold, distance_threshold, ep_thr);
-            bw |= (uint32_t)m << b;
+    if (small) {
+        // Adjacency over sorted positions, banded.  psl_merge_pair starts with the angle test, and the lines are sorted by
+        // angle, so for a row only the positions whose angle lies within the threshold - around the row's own angle, or
+        // across the +-pi/2 seam - can be set: three contiguous runs.  A row's candidate 32-pair words are listed in a
+        // bit mask, the (row, word) items are flattened by a prefix sum and evaluated densely; all other words are zero.
+        // (All n^2 pair tests, 97 % of them failing the angle test one lane at a time, were the kernel's main cost.)
+        float* sa = reinterpret_cast<float*>(LD.loc);  // angle by sorted position
+        int* wm = LD.tc;                               // candidate words of a row (bit w), n <= 1024 -> <= 32 words
+        int* pw = LD.nx;                               // exclusive prefix of popc(wm) over the rows
+        for (int p = tid; p < n; p += BS) sa[p] = M.angles[LD.order[p]];
+        for (int t = tid; t < n * words; t += BS) M.adj[(size_t)(t / words) * ROW + (t % words)] = 0;
+        __syncthreads();
+        const float tband = angle_threshold + 1e-3f;  // superset of the exact test
+        auto lower = [&](float v) { int lo = 0, hi = n; while (lo < hi) { const int mid = (lo + hi) >> 1; if (sa[mid] < v) lo = mid + 1; else hi = mid; } return lo; };   // first p with sa[p] >= v
+        auto upper = [&](float v) { int lo = 0, hi = n; while (lo < hi) { const int mid = (lo + hi) >> 1; if (sa[mid] <= v) lo = mid + 1; else hi = mid; } return lo; };  // first p with sa[p] > v
+        auto span = [](int lo, int hi) -> uint32_t {  // bits lo >> 5 .. hi >> 5
+            if (lo > hi) return 0u;
+            const int a = lo >> 5, b = hi >> 5;
+            const uint32_t upto = b >= 31 ? 0xffffffffu : ((1u << (b + 1)) - 1u);
+            return upto & ~((1u << a) - 1u);
+        };
+        __shared__ int s_tot, s_scan[4];
+        if (tid == 0) s_tot = 0;
+        __syncthreads();
+        for (int base = 0; base < n; base += BS) {
+            const int pi = base + tid;
+            uint32_t m = 0;
+            if (pi < n) {
+                const float a = sa[pi];
+                m = span(lower(a - tband), upper(a + tband) - 1);
+                m |= span(lower(a + (float)PSL_PI - tband), n - 1);
+                m |= span(0, upper(a - (float)PSL_PI + tband) - 1);
+                wm[pi] = (int)m;
+            }
+            int tot;
+            const int ex = psl_block_excl_scan256(__popc(m), s_scan, &tot);
+            if (pi < n) pw[pi] = s_tot + ex;
+            __syncthreads();
+            if (tid == 0) s_tot += tot;
+            __syncthreads();
         }
-        M.adj[(size_t)pi * ROW + wj] = bw;
+        const int T = s_tot;
+        for (int k = tid; k < T; k += BS) {
+            int lo = 0, hi = n;  // row = last pi with pw[pi] <= k
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (pw[mid] <= k) lo = mid + 1; else hi = mid; }
+            const int pi = lo - 1;
+            uint32_t m = (uint32_t)wm[pi];
+            for (int r = k - pw[pi]; r > 0; --r) m &= m - 1;
+            const int wj = __ffs(m) - 1;
+            uint32_t bw = 0;
+            const int idxi = LD.order[pi];
+            for (int b = 0; b < 32; ++b) {
+                const int pj = wj * 32 + b;
+                if (pj >= n || pj == pi) continue;
+                const int idxj = LD.order[pj];
+                const bool mm = pi < pj ? psl_merge_pair(src, M.angles, idxi, idxj, angle_threshold, distance_threshold, ep_thr)
+                                        : psl_merge_pair(src, M.angles, idxj, idxi, angle_threshold, distance_threshold, ep_thr);
+                bw |= (uint32_t)mm << b;
+            }
+            M.adj[(size_t)pi * ROW + wj] = bw;
+        }
+    } else {
+        for (int t = tid; t < n * words; t += BS) {  // adjacency over sorted positions, one 32-pair word per step
+            const int pi = t / words, wj = t - pi * words;
+            uint32_t bw = 0;
+            const int idxi = M.order[pi];
+            for (int b = 0; b < 32; ++b) {
+                const int pj = wj * 32 + b;
+                if (pj >= n || pj == pi) continue;
+                const int idxj = M.order[pj];
+                const bool m = pi < pj ? psl_merge_pair(src, M.angles, idxi, idxj, angle_threshold, distance_threshold, ep_thr)
+                                       : psl_merge_pair(src, M.angles, idxj, idxi, angle_threshold, distance_threshold, ep_thr);
+                bw |= (uint32_t)m << b;
+            }
+            M.adj[(size_t)pi * ROW + wj] = bw;
+        }
     }
     __syncthreads();
-    if (tid == 0) {
-        // clustering (:159-188), literally; the std::set<size_t> is a bitset over line indices
+    // clustering (:159-188).  The reference walks, per cluster, a breadth-first frontier: members of `to_check` are coded and
+    // appended in list order, their still-uncoded neighbours form the next frontier (a std::set: ascending index).  Small
+    // inputs run it on one wave: lane = frontier member (or adjacency word); a neighbour k is "still uncoded" when member
+    // q is processed iff it was uncoded at the start of the round and is not itself a member at a position <= q, which
+    // makes every member independent of the others; appends are ordered compactions.  Larger inputs: serial, literally.
+    __shared__ int s_cl[3];  // ncl, total, overflow
+    if (small) {
+        if (tid < 64) {
+            const int lane = tid;
+            const unsigned long long ltm = (1ull << lane) - 1ull;
+            int* code = LD.code;
+            const int* order = LD.order;
+            const int* posv = LD.pos;
+            uint32_t* bits = LD.bits;
+            int* to_check = LD.tc;
+            int* next = LD.nx;
+            int* qpos = LD.loc;
+            for (int k = lane; k < n; k += 64) qpos[k] = 0x7fffffff;
+            if (lane == 0) M.coff[0] = 0;
+            __builtin_amdgcn_wave_barrier();
+            int ncl = 0, total = 0;
+            bool overflow = false;
+            for (int i = 0; i < n && !overflow; ++i) {
+                if (code[i] >= 0) continue;
+                const int new_code = ncl;
+                __builtin_amdgcn_wave_barrier();
+                if (lane == 0) code[i] = new_code;
+                int ntc;
+                {   // neighbours of i in sorted-position order
+                    uint32_t v = lane < words ? M.adj[(size_t)posv[i] * ROW + lane] : 0u;
+                    const int c = __popc(v);
+                    int inc = c;
+#pragma unroll
+                    for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(inc, o); if (lane >= o) inc += u; }
+                    ntc = __shfl(inc, 63);
+                    int o = inc - c;
+                    while (v) { const int bb = __ffs(v) - 1; v &= v - 1; to_check[o++] = order[lane * 32 + bb]; }
+                }
+                if (total < PSL_MERGE_CLMAX) { if (lane == 0) M.clist[total] = i; ++total; } else overflow = true;
+                __builtin_amdgcn_wave_barrier();
+                while (ntc > 0 && !overflow) {
+                    if (lane < words) bits[lane] = 0;
+                    for (int q = lane; q < ntc; q += 64) qpos[to_check[q]] = q;
+                    __builtin_amdgcn_wave_barrier();
+                    for (int base = 0; base < ntc; base += 64) {
+                        const int q = base + lane;
+                        const int j = q < ntc ? to_check[q] : 0;
+                        const bool unc = q < ntc && code[j] < 0;
+                        const unsigned long long mu = __ballot(unc);
+                        const int at = total + __popcll(mu & ltm);
+                        if (unc && at < PSL_MERGE_CLMAX) M.clist[at] = j;
+                        total += __popcll(mu);
+                        if (total > PSL_MERGE_CLMAX) { total = PSL_MERGE_CLMAX; overflow = true; }
+                        if (q < ntc) {
+                            const uint32_t* row = M.adj + (size_t)posv[j] * ROW;
+                            for (int w = 0; w < words; ++w) {
+                                uint32_t v = row[w];
+                                while (v) {
+                                    const int bb = __ffs(v) - 1; v &= v - 1;
+                                    const int k = order[w * 32 + bb];
+                                    if (code[k] < 0 && !(qpos[k] <= q)) atomicOr(&bits[k >> 5], 1u << (k & 31));
+                                }
+                            }
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    for (int q = lane; q < ntc; q += 64) {
+                        const int j = to_check[q];
+                        if (code[j] < 0) code[j] = new_code;
+                        qpos[j] = 0x7fffffff;
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    {   // next frontier = set bits, ascending
+                        uint32_t v = lane < words ? bits[lane] : 0u;
+                        const int c = __popc(v);
+                        int inc = c;
+#pragma unroll
+                        for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(inc, o); if (lane >= o) inc += u; }
+                        ntc = __shfl(inc, 63);
+                        int o = inc - c;
+                        while (v) { const int bb = __ffs(v) - 1; v &= v - 1; next[o++] = lane * 32 + bb; }
+                    }
+                    int* t = to_check; to_check = next; next = t;
+                    __builtin_amdgcn_wave_barrier();
+                }
+                ++ncl;
+                if (lane == 0) M.coff[ncl] = total;
+            }
+            if (lane == 0) { s_cl[0] = ncl; s_cl[1] = total; s_cl[2] = overflow ? 1 : 0; }
+        }
+    } else if (tid == 0) {
         int ncl = 0, total = 0;
+        int* code = M.code;
+        const int* order = M.order;
+        const int* posv = M.pos;
+        uint32_t* bits = M.bits;
         int* to_check = M.work;
         int* next = M.work + PSL_MERGE_NMAX;
         bool overflow = false;
         M.coff[0] = 0;
         for (int i = 0; i < n && !overflow; ++i) {
-            if (M.code[i] >= 0) continue;
+            if (code[i] >= 0) continue;
             const int new_code = ncl;
-            M.code[i] = new_code;
+            code[i] = new_code;
             int ntc = 0;
             {
-                const uint32_t* row = M.adj + (size_t)M.pos[i] * ROW;
-                for (int w = 0; w < words; ++w) { uint32_t v = row[w]; while (v) { const int b = __ffs(v) - 1; v &= v - 1; to_check[ntc++] = M.order[w * 32 + b]; } }
+                const uint32_t* row = psl_merge_row(LD, M.adj + (size_t)posv[i] * ROW, words);
+                for (int w = 0; w < words; ++w) { uint32_t v = row[w]; while (v) { const int b = __ffs(v) - 1; v &= v - 1; to_check[ntc++] = order[w * 32 + b]; } }
             }
             if (total < PSL_MERGE_CLMAX) M.clist[total++] = i; else overflow = true;
             while (ntc > 0 && !overflow) {
-                for (int w = 0; w < words; ++w) M.bits[w] = 0;
+                for (int w = 0; w < words; ++w) bits[w] = 0;
                 for (int q = 0; q < ntc; ++q) {
                     const int j = to_check[q];
-                    if (M.code[j] < 0) { M.code[j] = new_code; if (total < PSL_MERGE_CLMAX) M.clist[total++] = j; else overflow = true; }
-                    const uint32_t* row = M.adj + (size_t)M.pos[j] * ROW;
+                    if (code[j] < 0) { code[j] = new_code; if (total < PSL_MERGE_CLMAX) M.clist[total++] = j; else overflow = true; }
+                    const uint32_t* row = psl_merge_row(LD, M.adj + (size_t)posv[j] * ROW, words);
                     for (int w = 0; w < words; ++w) {
                         uint32_t v = row[w];
-                        while (v) { const int b = __ffs(v) - 1; v &= v - 1; const int k = M.order[w * 32 + b]; if (M.code[k] < 0) M.bits[k >> 5] |= 1u << (k & 31); }
+                        while (v) { const int b = __ffs(v) - 1; v &= v - 1; const int k = order[w * 32 + b]; if (code[k] < 0) bits[k >> 5] |= 1u << (k & 31); }
                     }
                 }
                 ntc = 0;
-                for (int w = 0; w < words; ++w) { uint32_t v = M.bits[w]; while (v) { const int b = __ffs(v) - 1; v &= v - 1; next[ntc++] = w * 32 + b; } }
+                for (int w = 0; w < words; ++w) { uint32_t v = bits[w]; while (v) { const int b = __ffs(v) - 1; v &= v - 1; next[ntc++] = w * 32 + b; } }
                 int* t = to_check; to_check = next; next = t;
             }
             M.coff[++ncl] = total;
         }
+        s_cl[0] = ncl; s_cl[1] = total; s_cl[2] = overflow ? 1 : 0;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int ncl = s_cl[0], total = s_cl[1];
+        bool overflow = s_cl[2] != 0;
+        const int* order = small ? LD.order : M.order;
+        const int* posv = small ? LD.pos : M.pos;
+        const float* length = small ? LD.length : M.length;
         // sub-clusters (:190-228), appended behind the raw clusters
         const int raw_ncl = ncl;
-        int* loc = M.work + 2 * PSL_MERGE_NMAX;
-        uint8_t* clustered = reinterpret_cast<uint8_t*>(M.work + 3 * PSL_MERGE_NMAX);
+        int* loc = small ? LD.loc : M.work + 2 * PSL_MERGE_NMAX;
+        uint8_t* clustered = small ? LD.clustered : reinterpret_cast<uint8_t*>(M.work + 3 * PSL_MERGE_NMAX);
         int nfinal = 0;
         int* foff = M.coff + PSL_MERGE_NMAX + 1;
         foff[0] = total;
@@ -189,9 +389,9 @@ __device__ int psl_merge_pass(const MergeScratch& M, const float* src, float* ds
             }
             for (int a = 1; a < cs; ++a) {  // sort by length, descending (stable)
                 const int v = cl[a];
-                const float lv = M.length[v];
+                const float lv = length[v];
                 int b = a - 1;
-                while (b >= 0 && M.length[cl[b]] < lv) { cl[b + 1] = cl[b]; --b; }
+                while (b >= 0 && length[cl[b]] < lv) { cl[b + 1] = cl[b]; --b; }
                 cl[b + 1] = v;
             }
             for (int q = 0; q < cs; ++q) { loc[cl[q]] = q; clustered[q] = 0; }
@@ -199,12 +399,12 @@ __device__ int psl_merge_pass(const MergeScratch& M, const float* src, float* ds
                 if (clustered[j]) continue;
                 const int line_idx = cl[j];
                 if (total < PSL_MERGE_CLMAX) M.clist[total++] = line_idx; else overflow = true;
-                const uint32_t* row = M.adj + (size_t)M.pos[line_idx] * ROW;
+                const uint32_t* row = psl_merge_row(LD, M.adj + (size_t)posv[line_idx] * ROW, words);
                 for (int w = 0; w < words; ++w) {
                     uint32_t v = row[w];
                     while (v) {
                         const int b = __ffs(v) - 1; v &= v - 1;
-                        const int k = M.order[w * 32 + b];
+                        const int k = order[w * 32 + b];
                         clustered[loc[k]] = 1;
                         if (total < PSL_MERGE_CLMAX) M.clist[total++] = k; else overflow = true;
                     }
@@ -280,6 +480,7 @@ __global__ __launch_bounds__(256) void k_line_merge(LineParams P, MergeScratch M
                                                      PslKeyLine* __restrict__ kls, double* __restrict__ lineEq, int* __restrict__ nkl,
                                                      int* __restrict__ status) {
     __shared__ int s_i[4];
+    __shared__ MergeLds LD;
     const int frame = blockIdx.x, tid = threadIdx.x;
     const size_t f = (size_t)frame;
     MergeScratch M;
@@ -298,8 +499,8 @@ __global__ __launch_bounds__(256) void k_line_merge(LineParams P, MergeScratch M
     const float* src = seg + f * P.maxseg * 4;
     for (int i = tid; i < n * 4; i += 256) M.lines0[i] = src[i];
     __syncthreads();
-    n = psl_merge_pass(M, M.lines0, M.lines1, n, 0.05f, 5.f, 15.f, 30.f, s_i);
-    n = psl_merge_pass(M, M.lines1, M.lines0, n, 0.03f, 3.f, 30.f, 50.f, s_i);
+    n = psl_merge_pass(M, LD, M.lines0, M.lines1, n, 0.05f, 5.f, 15.f, 30.f, s_i);
+    n = psl_merge_pass(M, LD, M.lines1, M.lines0, n, 0.03f, 3.f, 30.f, 50.f, s_i);
     st |= s_i[1] << 1;
     // convertVec4fToKeyLine (:411-447)
     const float* L = M.lines0;
