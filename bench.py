@@ -44,7 +44,8 @@ MATCH_BYTES_PER_FRAME = 2 * 32 * NFEATURES + 8 * NFEATURES                      
 # per-kernel shares of that accounting: what each kernel must move at least
 STAGE_BYTES_PER_FRAME = {
     "orb.pyramid": WH + (P_PIX - WH),        # read level 0, write levels 1..7
-    "orb.fast": P_PIX,                       # read every level once
+    "orb.fast": P_PIX - WH,                  # read levels 1..7 once (the launch after the pyramid)
+    "orb.fast0": WH,                         # read level 0 once (the launch beside the pyramid)
     "orb.octree": 8 * 4000,                  # candidate list in + out (~4 k candidates x 8 B); not in §8(d)
     "orb.blur": P_PIX + P_PIX,               # read every level, write its blurred copy
     "orb.describe": 512 * NFEATURES + 60 * NFEATURES,
@@ -66,7 +67,7 @@ LINE_BYTES_PER_FRAME = 17040800 + 12800
 
 # stage -> kernels it launches (kernels per step); HBM traffic of a stage = sum over its launches
 STAGE_KERNELS = {
-    "orb.pyramid": [("k_pyr_resize_tiled", NLEVELS - 1)], "orb.fast": [("k_fast_cells4", 1)], "orb.octree": [("k_octree<256>", 1)],
+    "orb.pyramid": [("k_pyr_resize_tiled", NLEVELS - 1)], "orb.fast": [("k_fast_cells4<1>", 1)], "orb.fast0": [("k_fast_cells4<0>", 1)], "orb.octree": [("k_octree<256>", 1)],
     "orb.blur": [("k_blur7", 1)], "orb.describe": [("k_orient_describe", 1)],
     "match.grid": [("k_frame_import", 1), ("k_build_grid", 1)], "match.window": [("k_window_eval", 1), ("k_window_resolve<0, 4096, 1024>", 1)],
     "line.lsd_scale": [("k_lsd_scale_tiled", 1)], "line.lsd_grad": [("k_lsd_grad", 1)], "line.lsd_grow": [("k_lsd_grow3", 1)],
@@ -270,7 +271,7 @@ def main():
         tmpl = [torch.as_tensor(c_arr, device=dev), torch.as_tensor(k_arr, device=dev), torch.as_tensor(d_arr, device=dev), match, nmatches]
         gather = multigpu.ResultGather(tmpl, world, dev)
 
-    stage_names = ["orb.pyramid", "orb.fast", "orb.octree", "orb.blur", "orb.describe", "match.grid", "match.window",
+    stage_names = ["orb.pyramid", "orb.fast0", "orb.fast", "orb.octree", "orb.blur", "orb.describe", "match.grid", "match.window",
                    "line.lsd_scale", "line.lsd_grad", "line.lsd_grow", "line.merge", "line.lbd_pre", "line.lbd", "line.pair", "line.match", "line.good", "line.planes"]
 
     def read_stages():

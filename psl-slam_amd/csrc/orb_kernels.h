@@ -429,8 +429,9 @@ __device__ __forceinline__ int psl_fast_score_pol(const uint8_t* c, const int tp
     return A - 1;
 }
 
+template <int PART>  // 0: the launch for the level-0 cells that runs beside the pyramid; 1: any other launch (separate names in profiles)
 __global__ __launch_bounds__(256, 8) void k_fast_cells4(OrbParams P, FrameSrc S, const uint32_t* __restrict__ celltab,
-                                                      int* __restrict__ cellcnt, uint32_t* __restrict__ cellcand) {
+                                                      int* __restrict__ cellcnt, uint32_t* __restrict__ cellcand, int cell_begin) {
     __shared__ __attribute__((aligned(16))) uint32_t s_tile32[(PSL_MAXCELL + 6) * (PSL_FAST4_TP / 4) + 4];
     __shared__ __attribute__((aligned(16))) uint32_t s_score32[(PSL_MAXCELL + 2) * (PSL_FAST4_SP / 4)];
     __shared__ uint32_t s_rowmask[2][PSL_MAXCELL][2];  // [iniTh | minTh][row][x >> 5]: NMS survivors
@@ -442,6 +443,7 @@ __global__ __launch_bounds__(256, 8) void k_fast_cells4(OrbParams P, FrameSrc S,
 
     int cell, frame;
     if (!psl_item_frame(S, &cell, &frame)) return;
+    cell += cell_begin;  // the launch covers the cells [cell_begin, cell_begin + items)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t ct = celltab[cell];  // level | row << 8 | column << 20 of the cell (host table; one scalar load)
     const int level = (int)(ct & 0xff), i = (int)((ct >> 8) & 0xfff), j = (int)(ct >> 20);

@@ -13,16 +13,16 @@ void pslfe_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
-int pslfe_ctx::stage_begin(const char* name, hipEvent_t* a, hipEvent_t* b) {
+int pslfe_ctx::stage_begin(const char* name, hipEvent_t* a, hipEvent_t* b, hipStream_t on) {
     (void)name;
     PSL_HIP(hipEventCreate(a));
     PSL_HIP(hipEventCreate(b));
-    PSL_HIP(hipEventRecord(*a, stream));
+    PSL_HIP(hipEventRecord(*a, on ? on : stream));
     return PSLFE_OK;
 }
 
-int pslfe_ctx::stage_end(const char* name, hipEvent_t a, hipEvent_t b) {
-    PSL_HIP(hipEventRecord(b, stream));
+int pslfe_ctx::stage_end(const char* name, hipEvent_t a, hipEvent_t b, hipStream_t on) {
+    PSL_HIP(hipEventRecord(b, on ? on : stream));
     pending.push_back({a, b, name});
     return PSLFE_OK;
 }
@@ -80,6 +80,13 @@ int pslfe_ctx_create(int device, pslfe_ctx** out) {
         return PSLFE_E_HIP;
     }
     c->stream = c->own_stream;
+    if (hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) {
+        pslfe_ctx_destroy(c);
+        pslfe_set_error("pslfe_ctx_create: auxiliary stream / events failed");
+        return PSLFE_E_HIP;
+    }
     *out = c;
     return PSLFE_OK;
 }
@@ -88,7 +95,11 @@ void pslfe_ctx_destroy(pslfe_ctx* ctx) {
     if (!ctx) return;
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
+    if (ctx->aux_stream) hipStreamSynchronize(ctx->aux_stream);
     ctx->resolve_pending();
+    if (ctx->ev_fork) hipEventDestroy(ctx->ev_fork);
+    if (ctx->ev_join) hipEventDestroy(ctx->ev_join);
+    if (ctx->aux_stream) hipStreamDestroy(ctx->aux_stream);
     if (ctx->own_stream) hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }

@@ -40,6 +40,8 @@ struct pslfe_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;  // stream in use (own or external)
+    hipStream_t aux_stream = nullptr;              // second stream for independent kernels of one call (fork/join by events)
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool profile = false;
     std::string profile_only;  // non-empty: only this stage is timed (two events per step instead of two per stage)
     std::map<std::string, StageTimer> stages;
@@ -48,8 +50,8 @@ struct pslfe_ctx {
     std::vector<Pending> pending;
     int cu_count = 0;
 
-    int stage_begin(const char* name, hipEvent_t* a, hipEvent_t* b);
-    int stage_end(const char* name, hipEvent_t a, hipEvent_t b);
+    int stage_begin(const char* name, hipEvent_t* a, hipEvent_t* b, hipStream_t on = nullptr);
+    int stage_end(const char* name, hipEvent_t a, hipEvent_t b, hipStream_t on = nullptr);
     int resolve_pending();
 };
 
@@ -64,6 +66,20 @@ struct pslfe_ctx {
 #define PSL_STAGE_END(ctx, name)                                    \
     if (ev_on_) {                                                   \
         int rc_ = (ctx)->stage_end(name, ev_a_, ev_b_);             \
+        if (rc_) return rc_;                                        \
+    }
+
+// same, for kernels launched on another stream of the context
+#define PSL_STAGE_BEGIN_ON(ctx, name, st)                           \
+    hipEvent_t ev_a_ = nullptr, ev_b_ = nullptr;                    \
+    const bool ev_on_ = (ctx)->profile && ((ctx)->profile_only.empty() || (ctx)->profile_only == (name)); \
+    if (ev_on_) {                                                   \
+        int rc_ = (ctx)->stage_begin(name, &ev_a_, &ev_b_, st);     \
+        if (rc_) return rc_;                                        \
+    }
+#define PSL_STAGE_END_ON(ctx, name, st)                             \
+    if (ev_on_) {                                                   \
+        int rc_ = (ctx)->stage_end(name, ev_a_, ev_b_, st);         \
         if (rc_) return rc_;                                        \
     }
 
