@@ -1,12 +1,14 @@
 #!/usr/bin/env python3
 """bench.py — frames/sec of the PSL-SLAM per-frame feature front-end on MI355X.
 
-A "step" = one pass of the hot path over one batch of B synthetic 640x480 frames that are already
-resident in HBM: ORB extraction (pyramid, per-cell FAST, octree distribution, orientation, blur,
-rBRIEF) of all B frames + frame grid + ORBmatcher::SearchByProjection(cur,last) of every frame
-against its predecessor (BASELINE.json configs[1]: "640x480 synthetic RGB-D stream, ORB-only
-extract+match, 1xMI355X").  Results stay in HBM; with N > 1 every rank runs its own independent
-stream (weak scaling) and the per-frame result records are all-gathered over RCCL.
+A "step" = one pass of the hot path over one batch of B synthetic 640x480 RGB-D frames that are already
+resident in HBM.  Default workload = the one BASELINE.json's metric ("frames/sec ORB+line extract+match, 640x480
+RGB-D") is quoted on, configs[2]: ORB extraction (pyramid, per-cell FAST, octree distribution, orientation, blur,
+rBRIEF) + frame grid + ORBmatcher::SearchByProjection(cur,last) against the predecessor frame, and the line path
+(LSD, merge, LBD, top-200, LIL pairing, the RGB-D line glue of the Frame constructor, LSDmatcher::match), 4096
+frames per launch.  `--workload orb` = configs[1] (ORB-only extract+match, 256 frames per launch).  Results stay in
+HBM; with N > 1 every rank runs its own independent stream (weak scaling) and the per-frame result
+records are all-gathered over RCCL.
 
     python bench.py --gpus 1 --steps 20 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
@@ -173,8 +175,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=0, help="frames per step per GPU (default 256; 4096 for --workload lines)")
-    ap.add_argument("--workload", choices=["orb", "lines"], default="orb",
-                    help="orb = BASELINE configs[1] (ORB extract+match); lines = configs[2] (ORB + LSD/LBD + pairing, extract+match)")
+    ap.add_argument("--workload", choices=["orb", "lines"], default="lines",
+                    help="lines = BASELINE configs[2], the configuration of the headline metric (ORB + LSD/LBD + pairing + glue, "
+                         "extract+match); orb = configs[1] (ORB-only extract+match)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -331,7 +334,8 @@ def main():
         traffic, traffic_src = pmc_traffic(args.workload, dom, B)
         per_frame = ORB_BYTES_PER_FRAME + MATCH_BYTES_PER_FRAME + (LINE_BYTES_PER_FRAME if LINES else 0)
         out = {
-            "metric": "frames/sec ORB+line extract+match, 640x480" if LINES else "frames/sec ORB extract+match, 640x480",
+            "metric": ("frames/sec ORB+line extract+match, 640x480 RGB-D, 1/2/4/8 MI355X" if LINES
+                       else "frames/sec ORB-only extract+match, 640x480 RGB-D (BASELINE configs[1])"),
             "value": round(fps, 1), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
