@@ -178,6 +178,10 @@ def main():
     ap.add_argument("--workload", choices=["orb", "lines"], default="lines",
                     help="lines = BASELINE configs[2], the configuration of the headline metric (ORB + LSD/LBD + pairing + glue, "
                          "extract+match); orb = configs[1] (ORB-only extract+match)")
+    ap.add_argument("--streams", type=int, default=0, choices=[0, 1, 2],
+                    help="2: the line pipeline runs on its own context/stream beside the ORB pipeline (they are independent, as the "
+                         "two extractor objects of a Frame are; +6.5 %% frames/s measured, but stages then overlap and their event timings "
+                         "stop meaning what they say); 1 = default: everything on one stream, every stage timed alone")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -224,8 +228,13 @@ def main():
 
     BK = bench_kernels()
     le = None
+    nstreams = args.streams or 1
+    ctx_l = ctx
+    if LINES and nstreams == 2:
+        stream_l = torch.cuda.Stream(dev)
+        ctx_l = P.Context(local_rank, stream_l.cuda_stream)
     if LINES:
-        le = P.LINEextractor(1, 1.2, 200, 0.0, ctx=ctx, max_batch=B)
+        le = P.LINEextractor(1, 1.2, 200, 0.0, ctx=ctx_l, max_batch=B)
         le.extract_batch_device(frames_d.data_ptr(), B, W, H, W, W * H)
         _, _, _, _, klcap = le.results_device()
         lmatch = torch.full((B, klcap), -1, dtype=torch.int32, device=dev)
@@ -235,12 +244,13 @@ def main():
         dsc = sf.Scene(W, H, "struct", P_seed(rank))
         depth_h = np.stack([dsc.depth_u16(t).astype(np.float32) / np.float32(5000.0) for t in range(16)], 0)
         depth_d = torch.from_numpy(np.ascontiguousarray(np.concatenate([depth_h] * ((B + 15) // 16), 0)[:B])).to(dev)
-        glue = P.FrameGlue(max_lines=klcap, max_fans=4096, max_batch=B, ctx=ctx)
+        glue = P.FrameGlue(max_lines=klcap, max_fans=4096, max_batch=B, ctx=ctx_l)
         cam = np.zeros((), P.CAMERA_DTYPE)
         for k_, v_ in zip(P.CAMERA_DTYPE.names, (517.306408, 516.469215, 318.643040, 255.313989, 0, 0, 0, 0, 0, 40.0)):
             cam[k_] = np.float32(v_)
 
     gather = None
+    ctxs = [ctx] if ctx_l is ctx else [ctx, ctx_l]
 
     def step():
         orb.extract_batch_device(frames_d.data_ptr(), B, W, H, W, W * H)
@@ -266,7 +276,8 @@ def main():
             gather.submit([counts, kps, desc, match, nmatches])
         return counts
 
-    ctx.profile(True)
+    for c in ctxs:
+        c.profile(True)
     counts = step()  # first call allocates buffers / builds tables (not one of the W warm-up steps)
     torch.cuda.synchronize(dev)
     if world > 1:
@@ -280,22 +291,25 @@ def main():
     def read_stages():
         out = {}
         for s in stage_names:
-            ms, n = ctx.stage_time(s)
-            if n:
-                out[s] = {"ms_per_launch": ms / n, "launches": n}
+            for c in ctxs:
+                ms, n = c.stage_time(s)
+                if n:
+                    out[s] = {"ms_per_launch": ms / n, "launches": n}
         return out
 
     # Warm-up, with every stage timed: finds the dominant stage.  Each timed stage puts two HIP event records between
     # kernels (~10 us of idle GPU per stage boundary), so inside the timed region only the dominant stage is timed.
     if args.warmup > 0:
-        ctx.profile_reset()
+        for c in ctxs:
+            c.profile_reset()
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize(dev)
     warm = read_stages()
     dom = max(warm, key=lambda s: warm[s]["ms_per_launch"])
-    ctx.profile_reset()
-    ctx.profile_only(dom)
+    for c in ctxs:
+        c.profile_reset()
+        c.profile_only(dom)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize(dev)
@@ -315,13 +329,15 @@ def main():
         dt = float(t.item())
     dom_stage = read_stages()[dom]  # the dominant kernel over exactly the timed steps
     # per-stage table: a few extra steps after the timed region, every stage timed
-    ctx.profile_reset()
-    ctx.profile_only(None)
+    for c in ctxs:
+        c.profile_reset()
+        c.profile_only(None)
     for _ in range(min(args.steps, 5)):
         step()
     torch.cuda.synchronize(dev)
     stages = read_stages()
-    ctx.profile(False)
+    for c in ctxs:
+        c.profile(False)
     stages[dom] = dom_stage
     mean_kp = float(counts.float().mean().item())
     mean_matches = float(nmatches.float().mean().item())
@@ -345,6 +361,7 @@ def main():
                                    ("configs[1]: 640x480 synthetic RGB-D stream (desk-like), ORB 1000/1.2/8 FAST 20/7 "
                                     "extract + SearchByProjection(cur,last) match, frames resident in HBM"),
                        "frames_per_step_per_gpu": B, "mean_keypoints": round(mean_kp, 1), "mean_matches": round(mean_matches, 1),
+                       "streams": nstreams,
                        "multi_gpu": "independent stream per rank, RCCL all-gather of result records" if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
