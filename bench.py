@@ -5,7 +5,7 @@ A "step" = one pass of the hot path over one batch of B synthetic 640x480 RGB-D 
 resident in HBM.  Default workload = the one BASELINE.json's metric ("frames/sec ORB+line extract+match, 640x480
 RGB-D") is quoted on, configs[2]: ORB extraction (pyramid, per-cell FAST, octree distribution, orientation, blur,
 rBRIEF) + frame grid + ORBmatcher::SearchByProjection(cur,last) against the predecessor frame, and the line path
-(LSD, merge, LBD, top-200, LIL pairing, the RGB-D line glue of the Frame constructor, LSDmatcher::match), 4096
+(LSD, merge, LBD, top-200, LIL pairing, the RGB-D line glue of the Frame constructor, LSDmatcher::match), 6144
 frames per launch.  `--workload orb` = configs[1] (ORB-only extract+match, 256 frames per launch).  Results stay in
 HBM; with N > 1 every rank runs its own independent stream (weak scaling) and the per-frame result
 records are all-gathered over RCCL.
@@ -174,7 +174,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=0, help="frames per step per GPU (default 256; 4096 for --workload lines)")
+    ap.add_argument("--batch", type=int, default=0, help="frames per step per GPU (default 6144 = 6 LSD waves per SIMD; 256 for --workload orb)")
     ap.add_argument("--workload", choices=["orb", "lines"], default="lines",
                     help="lines = BASELINE configs[2], the configuration of the headline metric (ORB + LSD/LBD + pairing + glue, "
                          "extract+match); orb = configs[1] (ORB-only extract+match)")
@@ -202,7 +202,7 @@ def main():
     multigpu = import_module("psl_slam_amd.multigpu")
     P.build()
     LINES = args.workload == "lines"
-    B = args.batch or (4096 if LINES else 256)
+    B = args.batch or (6144 if LINES else 256)
     frames_h = synth_batch(B, P_seed(rank), style="struct" if LINES else "desk")
     frames_d = torch.from_numpy(frames_h).to(dev)
 

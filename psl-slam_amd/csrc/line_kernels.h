@@ -607,45 +607,26 @@ __device__ int lsdg_region_grow(const LsdW& F, int sx, int sy, double* reg_angle
     float sumdx = t0.z, sumdy = t0.w;
     lsdg_set(F, addr0);
     const int e = F.lane / 9, k = F.lane - e * 9, ky = k / 3, kx = k - ky * 3;
-    float a_n = PSL_LSD_NOTDEF, cs_n = 0.f, sn_n = 0.f;
-    uint32_t xy_n = 0;
-    bool u_n = true;
-    int pre = 0;
     int i = 0;
     while (i < reg_size) {
         const int nb = min(7, reg_size - i);
-        // every bitmap update and every prefetch issued so far must have landed before this round reads
+        // every bitmap update issued so far must have landed before this round reads (no prefetch of the next round:
+        // the kernel is bound by instruction issue, not latency - measured 4 % faster without it)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         float a = PSL_LSD_NOTDEF, sn = 0.f, cs = 0.f;
         uint32_t xy = 0;
+        int cidx = 0;
         bool u = true;
         if (F.lane < 63 && e < nb) {
-            if (e < pre) { a = a_n; cs = cs_n; sn = sn_n; xy = xy_n; u = u_n; }
-            else {
-                const uint32_t rp = lsdw_reg(F, i + e, reg_size);
-                const int nx = (int)(rp & 0xffff) + kx - 1, ny = (int)(rp >> 16) + ky - 1;
-                if (nx >= 0 && nx < F.W && ny >= 0 && ny < F.H) {
-                    const int c = nx + ny * F.W;
-                    a = F.ang[c];
-                    const float2 t = *reinterpret_cast<const float2*>(&F.trig[c]);
-                    cs = t.x; sn = t.y;
-                    xy = (uint32_t)nx | ((uint32_t)ny << 16);
-                    u = lsdg_used(F, c);
-                }
-            }
-        }
-        pre = min(7, reg_size - (i + nb));
-        a_n = PSL_LSD_NOTDEF; u_n = true;
-        if (F.lane < 63 && e < pre) {
-            const uint32_t rp = lsdw_reg(F, i + nb + e, reg_size);
+            const uint32_t rp = lsdw_reg(F, i + e, reg_size);
             const int nx = (int)(rp & 0xffff) + kx - 1, ny = (int)(rp >> 16) + ky - 1;
             if (nx >= 0 && nx < F.W && ny >= 0 && ny < F.H) {
-                const int c = nx + ny * F.W;
-                a_n = F.ang[c];
-                const float2 t = *reinterpret_cast<const float2*>(&F.trig[c]);
-                cs_n = t.x; sn_n = t.y;
-                xy_n = (uint32_t)nx | ((uint32_t)ny << 16);
-                u_n = lsdg_used(F, c);
+                cidx = nx + ny * F.W;
+                a = F.ang[cidx];
+                const float2 t = *reinterpret_cast<const float2*>(&F.trig[cidx]);
+                cs = t.x; sn = t.y;
+                xy = (uint32_t)nx | ((uint32_t)ny << 16);
+                u = lsdg_used(F, cidx);
             }
         }
         const bool cand0 = a != PSL_LSD_NOTDEF;
@@ -657,11 +638,11 @@ __device__ int lsdg_region_grow(const LsdW& F, int sx, int sy, double* reg_angle
             if (!m) break;
             const int L = __ffsll((long long)m) - 1;
             const uint32_t xyL = (uint32_t)__builtin_amdgcn_readlane((int)xy, L);
+            const int cL = __builtin_amdgcn_readlane(cidx, L);
             const float csL = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cs), L));
             const float snL = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sn), L));
-            if (cand0 && xy == xyL) u = true;                          // duplicates of this pixel in the current round
-            if (a_n != PSL_LSD_NOTDEF && xy_n == xyL) u_n = true;      // ... and in the prefetched next round
-            lsdg_set(F, (int)(xyL & 0xffff) + (int)(xyL >> 16) * F.W);
+            if (cand0 && xy == xyL) u = true;  // duplicates of this pixel in the current round
+            lsdg_set(F, cL);
             lsdw_push(F, reg_size, xyL);
             ++reg_size;
             sumdx = PSL_FADD(sumdx, csL);
@@ -870,7 +851,8 @@ __global__ __launch_bounds__(64) void k_lsd_grow2(LineParams P, const float* __r
 
 
 #ifndef PSL_GROW_WAVES
-#define PSL_GROW_WAVES 5   // waves per SIMD the register budget allows; measured: no gain from 7 (spills, throughput-bound)
+#define PSL_GROW_WAVES 6   // waves per SIMD the register budget allows: 6 (80 VGPRs, a few spills) with 6144 frames in flight is
+                           // 9 % faster per frame than 5 with 4096-5120; 7 (72 VGPRs, 18 spills) gains nothing more
 #endif
 __global__ __launch_bounds__(64, PSL_GROW_WAVES) void k_lsd_grow3(LineParams P, const float* __restrict__ angdeg, const double* __restrict__ modgrad,
                                                    const float4* __restrict__ trig, uint32_t* __restrict__ usedbits, uint32_t* __restrict__ reg,
