@@ -46,8 +46,8 @@ MATCH_BYTES_PER_FRAME = 2 * 32 * NFEATURES + 8 * NFEATURES                      
 # per-kernel shares of that accounting: what each kernel must move at least
 STAGE_BYTES_PER_FRAME = {
     "orb.pyramid": WH + (P_PIX - WH),        # read level 0, write levels 1..7
-    "orb.fast": P_PIX - WH,                  # read levels 1..7 once (the launch after the pyramid)
-    "orb.fast0": WH,                         # read level 0 once (the launch beside the pyramid)
+    "orb.fast": P_PIX,                       # read every level once
+    "orb.fast0": WH,                         # PSLFE_OVERLAP=1 only: level 0 in its own launch beside the pyramid
     "orb.octree": 8 * 4000,                  # candidate list in + out (~4 k candidates x 8 B); not in §8(d)
     "orb.blur": P_PIX + P_PIX,               # read every level, write its blurred copy
     "orb.describe": 512 * NFEATURES + 60 * NFEATURES,
@@ -66,6 +66,8 @@ STAGE_BYTES_PER_FRAME = {
     "line.planes": 4096 * 16 + 200 * 60,
 }
 LINE_BYTES_PER_FRAME = 17040800 + 12800
+if os.environ.get("PSLFE_OVERLAP"):
+    STAGE_BYTES_PER_FRAME["orb.fast"] = P_PIX - WH  # levels 1..7 in the launch after the pyramid
 
 # stage -> kernels it launches (kernels per step); HBM traffic of a stage = sum over its launches
 STAGE_KERNELS = {
