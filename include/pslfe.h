@@ -309,6 +309,33 @@ int pslfe_orb_search_by_projection_last(pslfe_frame* cur, int slot, const PslPro
 int pslfe_orb_search_by_projection_map(pslfe_frame* cur, int slot, const PslProjQuery* queries, const uint8_t* qdesc,
                                        int nq, const uint8_t* taken, float nnratio, int32_t* match, int32_t* assigned,
                                        int* nmatches);
+/* == ORBmatcher::SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th, ORBdist) src/ORBmatcher.cc:1472-1599
+ *    (relocalisation) after the host has projected the keyframe's map points (skipping bad ones and those in
+ *    sAlreadyFound): window search as above, but every occupied keypoint is skipped (taken[c] != 0 <=>
+ *    CurrentFrame.mvpMapPoints[c] != NULL), every match occupies its keypoint, there is no stereo gate and the
+ *    distance gate is ORBdist.  queries[i].angle = pKF->mvKeysUn[i].angle; `blocks` is ignored (always 1). */
+int pslfe_orb_search_by_projection_kf(pslfe_frame* cur, int slot, const PslProjQuery* queries, const uint8_t* qdesc, int nq,
+                                      const uint8_t* taken, int orb_dist, int check_orientation, int32_t* match,
+                                      int32_t* assigned, int* nmatches);
+
+/* == ORBmatcher::SearchByBoW(pKF, F, vpMapPointMatches) src/ORBmatcher.cc:159-288, from the point where the two DBoW2
+ *    FeatureVectors are walked.  DBoW2 (vocabulary, FeatureVector) stays on the host; the caller passes
+ *    fidx: the frame's FeatureVector flattened in node order (F.mFeatVec: for node ascending, its vIndicesF);
+ *    one query per keyframe feature in the reference's iteration order (common nodes ascending, vIndicesKF order,
+ *    NULL / bad map points dropped): the run [start, start+len) of fidx that is its node's vIndicesF, its descriptor
+ *    (qdesc, 32 B) and pKF->mvKeysUn[realIdxKF].angle.
+ *    Slot `slot` of `f` holds the frame's keypoints (mvKeys angles) and descriptors.  TH_LOW = 50, ratio test with
+ *    mfNNratio against the second best (256 when there is none), a frame feature matched by an earlier query is skipped
+ *    (:206-207), rotation histogram as elsewhere.  match[i] = frame feature of query i or -1; assigned[f] = query whose
+ *    map point ends up in vpMapPointMatches[f]; *nmatches = the return value. */
+typedef struct PslBowQuery {
+    int32_t start, len;
+    float angle;
+} PslBowQuery;
+int pslfe_orb_search_by_bow(pslfe_frame* f, int slot, const int32_t* fidx, int nfidx, const PslBowQuery* queries,
+                            const uint8_t* qdesc, int nq, float nnratio, int check_orientation, int32_t* match,
+                            int32_t* assigned, int* nmatches);
+
 /* Batched, HBM-resident form of pslfe_orb_search_by_projection_last: pair p searches slot
  * slot0 + p with d_nq[p] queries at d_queries + p*qstride (descriptors at d_qdesc + p*qstride*32),
  * writes d_match + p*qstride and d_nmatches[p].  Asynchronous on the context's stream. */

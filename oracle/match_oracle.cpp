@@ -306,3 +306,112 @@ void pso_frame_post_rgbd(const PsoKeyPoint* kps, int n, const float* depth, int 
 }
 
 }  // extern "C"
+
+// ---- SURVEY.md §8a row a18 ---------------------------------------------------------------------------------------
+//   ORBmatcher::SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th, ORBdist)   src/ORBmatcher.cc:1472-1599
+//        (relocalisation): window search like (cur,last) but every occupied keypoint is skipped, every match occupies,
+//        no stereo gate, threshold = ORBdist; projection / sAlreadyFound / scale prediction stay with the caller.
+//   ORBmatcher::SearchByBoW(pKF, F, vpMapPointMatches)                              src/ORBmatcher.cc:159-288
+//        from the point where the two DBoW2 FeatureVectors are walked: the caller (DBoW2 stays on the host) passes, in the
+//        reference's iteration order (nodes ascending, vIndicesKF order, bad/NULL map points dropped), one query per
+//        keyframe feature: its descriptor, its angle and the run [start, start+len) of the frame's node list
+//        (`fidx` = the frame's FeatureVector flattened in node order).
+extern "C" {
+
+int pso_search_by_projection_kf(const PsoKeyPoint* kps, const uint8_t* desc, int n, float minX, float minY, float maxX, float maxY,
+                                const PsoProjQuery* q, const uint8_t* qdesc, int nq, const uint8_t* taken, int orbDist, int checkOri,
+                                int* match, int* assigned) {
+    Grid* g = new Grid();
+    g->build(kps, n, minX, minY, maxX, maxY);
+    int nmatches = 0;
+    std::vector<int> rotHist[HISTO_LENGTH];
+    const float factor = 1.0f / HISTO_LENGTH;
+    std::vector<int> owner(n, -1);
+    std::vector<char> occupied(n, 0);  // CurrentFrame.mvpMapPoints[i2] != NULL
+    for (int i = 0; i < n; ++i) occupied[i] = taken ? (taken[i] != 0) : 0;
+    std::vector<std::pair<int, int>> histEntries[HISTO_LENGTH];
+    for (int i = 0; i < nq; ++i) {
+        match[i] = -1;
+        const std::vector<int> cand = g->area(q[i].u, q[i].v, q[i].radius, q[i].min_level, q[i].max_level);
+        if (cand.empty()) continue;
+        int bestDist = 256, bestIdx2 = -1;
+        for (int i2 : cand) {
+            if (occupied[i2]) continue;
+            const int dist = descriptor_distance(qdesc + (size_t)i * 32, desc + (size_t)i2 * 32);
+            if (dist < bestDist) { bestDist = dist; bestIdx2 = i2; }
+        }
+        if (bestDist <= orbDist) {
+            owner[bestIdx2] = i;
+            occupied[bestIdx2] = 1;
+            match[i] = bestIdx2;
+            nmatches++;
+            if (checkOri) {
+                float rot = q[i].angle - kps[bestIdx2].angle;
+                if (rot < 0.0) rot += 360.0f;
+                int bin = (int)std::round(rot * factor);
+                if (bin == HISTO_LENGTH) bin = 0;
+                rotHist[bin].push_back(bestIdx2);
+                histEntries[bin].push_back(std::make_pair(i, bestIdx2));
+            }
+        }
+    }
+    if (checkOri) {
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        three_maxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int b = 0; b < HISTO_LENGTH; b++)
+            if (b != ind1 && b != ind2 && b != ind3)
+                for (auto& e : histEntries[b]) { owner[e.second] = -1; match[e.first] = -1; nmatches--; }
+    }
+    if (assigned) for (int i = 0; i < n; ++i) assigned[i] = owner[i];
+    delete g;
+    return nmatches;
+}
+
+// run[2*i], run[2*i+1]: start and length of query i's candidate run in fidx; qangle: pKF->mvKeysUn[realIdxKF].angle;
+// fangle: F.mvKeys[.].angle.  match[i] = frame feature given to query i or -1; assigned[f] = query owning frame feature f.
+int pso_search_by_bow(const uint8_t* fdesc, const float* fangle, int nf, const int32_t* fidx, const int32_t* run, const uint8_t* qdesc,
+                      const float* qangle, int nq, float nnratio, int checkOri, int* match, int* assigned) {
+    const int TH_LOW = 50;
+    int nmatches = 0;
+    std::vector<int> rotHist[HISTO_LENGTH];
+    std::vector<std::pair<int, int>> histEntries[HISTO_LENGTH];
+    const float factor = 1.0f / HISTO_LENGTH;
+    std::vector<int> owner(nf, -1);  // vpMapPointMatches[realIdxF] as a query index
+    for (int i = 0; i < nq; ++i) {
+        match[i] = -1;
+        int bestDist1 = 256, bestIdxF = -1, bestDist2 = 256;
+        for (int p = run[2 * i]; p < run[2 * i] + run[2 * i + 1]; ++p) {
+            const int realIdxF = fidx[p];
+            if (owner[realIdxF] >= 0) continue;
+            const int dist = descriptor_distance(qdesc + (size_t)i * 32, fdesc + (size_t)realIdxF * 32);
+            if (dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; bestIdxF = realIdxF; }
+            else if (dist < bestDist2) { bestDist2 = dist; }
+        }
+        if (bestDist1 <= TH_LOW) {
+            if (static_cast<float>(bestDist1) < nnratio * static_cast<float>(bestDist2)) {
+                owner[bestIdxF] = i;
+                match[i] = bestIdxF;
+                if (checkOri) {
+                    float rot = qangle[i] - fangle[bestIdxF];
+                    if (rot < 0.0) rot += 360.0f;
+                    int bin = (int)std::round(rot * factor);
+                    if (bin == HISTO_LENGTH) bin = 0;
+                    rotHist[bin].push_back(bestIdxF);
+                    histEntries[bin].push_back(std::make_pair(i, bestIdxF));
+                }
+                nmatches++;
+            }
+        }
+    }
+    if (checkOri) {
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        three_maxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int b = 0; b < HISTO_LENGTH; b++)
+            if (b != ind1 && b != ind2 && b != ind3)
+                for (auto& e : histEntries[b]) { owner[e.second] = -1; match[e.first] = -1; nmatches--; }
+    }
+    if (assigned) for (int f = 0; f < nf; ++f) assigned[f] = owner[f];
+    return nmatches;
+}
+
+}  // extern "C"

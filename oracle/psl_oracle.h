@@ -105,6 +105,12 @@ void pso_image_bounds(int cols, int rows, const float* K, const float* dist, flo
 void pso_frame_post_rgbd(const PsoKeyPoint* kps, int n, const float* depth, int w, int h, int dstride, const float* K, const float* dist,
                          float mbf, PsoKeyPoint* kpsUn, float* mvDepth, float* mvuRight);
 
+int pso_search_by_projection_kf(const PsoKeyPoint* kps, const uint8_t* desc, int n, float minX, float minY, float maxX, float maxY,
+                                const PsoProjQuery* q, const uint8_t* qdesc, int nq, const uint8_t* taken, int orbDist, int checkOri,
+                                int* match, int* assigned);
+int pso_search_by_bow(const uint8_t* fdesc, const float* fangle, int nf, const int32_t* fidx, const int32_t* run, const uint8_t* qdesc,
+                      const float* qangle, int nq, float nnratio, int checkOri, int* match, int* assigned);
+
 /* RGB-D line glue of the Frame constructor (glue_oracle.cpp) */
 void pso_line_good(const PsoKeyLine* kls, int n, const float* depth, int cols, int rows, int dstride, const float* cam, uint32_t seed,
                    double* lines3d, float* lineEq);

@@ -26,6 +26,7 @@ KEYLINE_DTYPE = np.dtype([("angle", "<f4"), ("class_id", "<i4"), ("octave", "<i4
                           ("lineLength", "<f4"), ("numOfPixels", "<i4")])
 PROJQUERY_DTYPE = np.dtype([("u", "<f4"), ("v", "<f4"), ("radius", "<f4"), ("ur", "<f4"), ("min_level", "<i4"),
                             ("max_level", "<i4"), ("angle", "<f4"), ("blocks", "<i4")])
+BOWQUERY_DTYPE = np.dtype([("start", "<i4"), ("len", "<i4"), ("angle", "<f4")])
 CAMERA_DTYPE = np.dtype([(k, "<f4") for k in ("fx", "fy", "cx", "cy", "k1", "k2", "p1", "p2", "k3", "bf")])
 assert KEYPOINT_DTYPE.itemsize == 28 and KEYLINE_DTYPE.itemsize == 68 and PROJQUERY_DTYPE.itemsize == 32
 
@@ -386,6 +387,38 @@ class ORBmatcher:
         """SearchByProjection(CurrentFrame, LastFrame, th, bMono) src/ORBmatcher.cc:1328."""
         return self._run(lib().pslfe_orb_search_by_projection_last, frame, slot, queries, qdesc, taken,
                          C.c_int(1 if self.mbCheckOrientation else 0))
+
+    def SearchByProjectionKF(self, frame, slot, queries, qdesc, taken=None, ORBdist=100):
+        """SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th, ORBdist) src/ORBmatcher.cc:1472 (relocalisation)."""
+        queries = np.ascontiguousarray(queries, PROJQUERY_DTYPE)
+        qdesc = np.ascontiguousarray(qdesc, np.uint8)
+        nq = len(queries)
+        match = np.full(max(nq, 1), -1, np.int32)
+        assigned = np.full(max(frame.n[slot], 1), -1, np.int32)
+        tk = None if taken is None else np.ascontiguousarray(taken, np.uint8)
+        nm = C.c_int()
+        _check(lib().pslfe_orb_search_by_projection_kf(frame._h, C.c_int(slot), _ptr(queries), _ptr(qdesc), C.c_int(nq), _ptr(tk),
+                                                       C.c_int(ORBdist), C.c_int(1 if self.mbCheckOrientation else 0), _ptr(match),
+                                                       _ptr(assigned), C.byref(nm)), "pslfe_orb_search_by_projection_kf")
+        return nm.value, match[:nq], assigned[:frame.n[slot]]
+
+    def SearchByBoW(self, frame, slot, fidx, runs, qangle, qdesc):
+        """SearchByBoW(pKF, F, vpMapPointMatches) src/ORBmatcher.cc:159 on host-provided FeatureVectors: fidx = F.mFeatVec
+        flattened in node order; runs[i] = (start, len) of query i's node in fidx; qangle / qdesc per query."""
+        fidx = np.ascontiguousarray(fidx, np.int32)
+        q = np.zeros(len(runs), BOWQUERY_DTYPE)
+        if len(runs):
+            r = np.asarray(runs, np.int32).reshape(-1, 2)
+            q["start"], q["len"], q["angle"] = r[:, 0], r[:, 1], np.asarray(qangle, np.float32)
+        qdesc = np.ascontiguousarray(qdesc, np.uint8)
+        nq = len(q)
+        match = np.full(max(nq, 1), -1, np.int32)
+        assigned = np.full(max(frame.n[slot], 1), -1, np.int32)
+        nm = C.c_int()
+        _check(lib().pslfe_orb_search_by_bow(frame._h, C.c_int(slot), _ptr(fidx), C.c_int(len(fidx)), _ptr(q), _ptr(qdesc), C.c_int(nq),
+                                             C.c_float(self.mfNNratio), C.c_int(1 if self.mbCheckOrientation else 0), _ptr(match),
+                                             _ptr(assigned), C.byref(nm)), "pslfe_orb_search_by_bow")
+        return nm.value, match[:nq], assigned[:frame.n[slot]]
 
     def SearchByProjectionMap(self, frame, slot, queries, qdesc, taken=None):
         """SearchByProjection(F, vpMapPoints, th) src/ORBmatcher.cc:45."""

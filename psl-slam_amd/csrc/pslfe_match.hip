@@ -229,6 +229,10 @@ struct MatchArgs {
     int* nmatches;
     uint32_t* topk;   // [pair][qstride][PSL_TOPK]: the smallest keys (dist << 16 | CSR position) of every query, ascending
     uint8_t* more;    // [pair][qstride]: the query has more than PSL_TOPK gated candidates
+    int th;           // descriptor-distance gate of the decision: TH_HIGH, ORBdist or TH_LOW
+    int no_stereo;    // skip the mvuRight gate (SearchByProjection(cur,KF), SearchByBoW)
+    const int* fidx;  // != NULL: candidates of a query are the run [min_level, min_level + max_level) of this index list
+                      // (the frame's DBoW2 FeatureVector flattened in node order) instead of a grid window
 };
 
 #define PSL_KEY_INF 0xffffffffu
@@ -274,8 +278,19 @@ struct WindowCols {
     bool checkLevels;
 };
 
-__device__ __forceinline__ WindowCols psl_window_cols(const FrameView& V, const PslProjQuery& q) {
+__device__ __forceinline__ WindowCols psl_window_cols(const FrameView& V, const PslProjQuery& q, const int* fidx) {
     const int lane = threadIdx.x & 63;
+    if (fidx) {  // one run: the frame's features under the query's vocabulary node
+        WindowCols W;
+        W.start = lane == 0 ? q.min_level : 0;
+        const int len = lane == 0 ? (q.max_level > 0 ? q.max_level : 0) : 0;
+        W.incl = len > 0 ? len : 0;
+        W.incl = __shfl(W.incl, 0);  // inclusive counts: every lane >= 0 holds the total
+        W.excl = lane == 0 ? 0 : W.incl;
+        W.T = W.incl;
+        W.checkLevels = false;
+        return W;
+    }
     const FrameMeta& M = V.M;
     const float r = q.radius;
     const int minCX = max(0, (int)__builtin_floorf(PSL_FMUL(PSL_FSUB(PSL_FSUB(q.u, M.minX), r), M.invW)));
@@ -305,7 +320,7 @@ __device__ __forceinline__ WindowCols psl_window_cols(const FrameView& V, const 
 // window, stereo (:1405-1411), taken initially (:1401-1403), taken by an earlier query of this call (blocker != NULL).
 // Called by all 64 lanes (shuffles inside).
 __device__ __forceinline__ uint32_t psl_window_key(const FrameView& V, const PslProjQuery& q, const uint32_t* qd, const uint8_t* taken,
-                                                   const int* blocker, int qi, const WindowCols& W, int j) {
+                                                   const int* blocker, int qi, const WindowCols& W, int j, const int* fidx, int no_stereo) {
     int c = 0;  // number of columns whose inclusive count is <= j == the column of candidate j
 #pragma unroll
     for (int step = 32; step > 0; step >>= 1) {
@@ -318,18 +333,20 @@ __device__ __forceinline__ uint32_t psl_window_key(const FrameView& V, const Psl
     if (j < W.T) {
         const float r = q.radius;
         const int p = cs + (j - ce);
-        const int i2 = V.gidx[p];
+        const int i2 = fidx ? fidx[p] : V.gidx[p];
         const float2 xy = *reinterpret_cast<const float2*>(&V.kps[i2].x);
         const int octave = V.kps[i2].octave;
         const float ur = V.uright[i2];
         const uint4 d0 = *reinterpret_cast<const uint4*>(V.desc + (size_t)i2 * 8);
         const uint4 d1 = *reinterpret_cast<const uint4*>(V.desc + (size_t)i2 * 8 + 4);
-        bool ok = i2 < V.n;
-        if (W.checkLevels) ok = ok && !(octave < q.min_level) && !(q.max_level >= 0 && octave > q.max_level);
-        ok = ok && (__builtin_fabsf(PSL_FSUB(xy.x, q.u)) < r && __builtin_fabsf(PSL_FSUB(xy.y, q.v)) < r);
+        bool ok = i2 >= 0 && i2 < V.n;
+        if (!fidx) {
+            if (W.checkLevels) ok = ok && !(octave < q.min_level) && !(q.max_level >= 0 && octave > q.max_level);
+            ok = ok && (__builtin_fabsf(PSL_FSUB(xy.x, q.u)) < r && __builtin_fabsf(PSL_FSUB(xy.y, q.v)) < r);
+        }
         if (taken) ok = ok && !taken[i2];
         if (blocker) ok = ok && !(blocker[i2] < qi);
-        ok = ok && !(ur > 0 && __builtin_fabsf(PSL_FSUB(q.ur, ur)) > r);
+        if (!no_stereo) ok = ok && !(ur > 0 && __builtin_fabsf(PSL_FSUB(q.ur, ur)) > r);
         const int dist = __popc(qd[0] ^ d0.x) + __popc(qd[1] ^ d0.y) + __popc(qd[2] ^ d0.z) + __popc(qd[3] ^ d0.w) +
                          __popc(qd[4] ^ d1.x) + __popc(qd[5] ^ d1.y) + __popc(qd[6] ^ d1.z) + __popc(qd[7] ^ d1.w);
         if (ok) key = ((uint32_t)dist << 16) | (uint32_t)p;
@@ -368,11 +385,11 @@ __global__ __launch_bounds__(256) void k_window_eval(MatchArgs A) {
 #pragma unroll
     for (int k = 0; k < 8; ++k) qd[k] = QD[k];
     const uint8_t* taken = A.taken ? A.taken + (size_t)pair * A.S.cap : nullptr;
-    const WindowCols W = psl_window_cols(V, q);
+    const WindowCols W = psl_window_cols(V, q, A.fidx);
     uint32_t best = PSL_KEY_INF;  // lanes 0..PSL_TOPK-1: running smallest keys, ascending
     int cnt = 0;
     for (int base = 0; base < W.T; base += 64) {
-        uint32_t key = psl_window_key(V, q, qd, taken, nullptr, qi, W, base + lane);
+        uint32_t key = psl_window_key(V, q, qd, taken, nullptr, qi, W, base + lane, A.fidx, A.no_stereo);
         cnt += __popcll(__ballot(key != PSL_KEY_INF));
         key = psl_wave_sort(key);
         if (base > 0) {  // merge this round's smallest with the running ones
@@ -415,6 +432,7 @@ __global__ __launch_bounds__(BS) void k_window_resolve(MatchArgs A) {
     const uint8_t* taken = A.taken ? A.taken + (size_t)pair * S.cap : nullptr;
     const uint32_t* TK = A.topk + (size_t)pair * A.qstride * PSL_TOPK;
     const uint8_t* MORE = A.more + (size_t)pair * A.qstride;
+    const int* posmap = A.fidx ? A.fidx : V.gidx;  // candidate position -> keypoint of the frame
 
     // candidate lists of this thread's queries: keys (distance << 16 | CSR position, ascending, INF-terminated) and
     // per candidate keypoint index | octave << 12
@@ -440,8 +458,8 @@ __global__ __launch_bounds__(BS) void k_window_resolve(MatchArgs A) {
 #pragma unroll
         for (int h = 0; h < PSL_TOPK / 2; ++h) {
             uint32_t c0 = 0, c1 = 0;
-            if (K[r][2 * h] != PSL_KEY_INF) { c0 = (uint32_t)V.gidx[K[r][2 * h] & 0xffff]; if (MODE == 1) c0 |= (uint32_t)V.kps[c0].octave << 12; }
-            if (K[r][2 * h + 1] != PSL_KEY_INF) { c1 = (uint32_t)V.gidx[K[r][2 * h + 1] & 0xffff]; if (MODE == 1) c1 |= (uint32_t)V.kps[c1].octave << 12; }
+            if (K[r][2 * h] != PSL_KEY_INF) { c0 = (uint32_t)posmap[K[r][2 * h] & 0xffff]; if (MODE == 1) c0 |= (uint32_t)V.kps[c0].octave << 12; }
+            if (K[r][2 * h + 1] != PSL_KEY_INF) { c1 = (uint32_t)posmap[K[r][2 * h + 1] & 0xffff]; if (MODE == 1) c1 |= (uint32_t)V.kps[c1].octave << 12; }
             CP[r][h] = c0 | (c1 << 16);
         }
 #define PSL_CI(r, e) ((CP[r][(e) >> 1] >> (16 * ((e) & 1))) & 0xffffu)
@@ -455,10 +473,14 @@ __global__ __launch_bounds__(BS) void k_window_resolve(MatchArgs A) {
     auto decide = [&](uint32_t k1, uint32_t c1, uint32_t k2, uint32_t c2) -> int {
         if (k1 == PSL_KEY_INF) return -1;
         const int bestDist = (int)(k1 >> 16);
-        bool ok = bestDist <= PSL_TH_HIGH;
+        bool ok = bestDist <= A.th;
         if (MODE == 1 && ok && k2 != PSL_KEY_INF) {
             const int bestDist2 = (int)(k2 >> 16);
             if ((c1 >> 12) == (c2 >> 12) && (float)bestDist > PSL_FMUL(A.nnratio, (float)bestDist2)) ok = false;  // (:118-121)
+        }
+        if (MODE == 2 && ok) {  // SearchByBoW (:229-231): ratio against the second best, 256 when there is none
+            const int bestDist2 = k2 != PSL_KEY_INF ? (int)(k2 >> 16) : 256;
+            if (!((float)bestDist < PSL_FMUL(A.nnratio, (float)bestDist2))) ok = false;
         }
         return ok ? (int)(c1 & 0xfff) : -1;
     };
@@ -505,10 +527,10 @@ __global__ __launch_bounds__(BS) void k_window_resolve(MatchArgs A) {
                 uint32_t qd[8];
 #pragma unroll
                 for (int k = 0; k < 8; ++k) qd[k] = QD[(size_t)qi * 8 + k];
-                const WindowCols W = psl_window_cols(V, q);
+                const WindowCols W = psl_window_cols(V, q, A.fidx);
                 uint32_t t0 = PSL_KEY_INF, t1 = PSL_KEY_INF;  // two smallest keys
                 for (int base = 0; base < W.T; base += 64) {
-                    const uint32_t key = psl_window_key(V, q, qd, taken, blk, qi, W, base + lane);
+                    const uint32_t key = psl_window_key(V, q, qd, taken, blk, qi, W, base + lane, A.fidx, A.no_stereo);
                     if (key < t0) { t1 = t0; t0 = key; } else if (key < t1) t1 = key;
                 }
 #pragma unroll
@@ -519,8 +541,8 @@ __global__ __launch_bounds__(BS) void k_window_resolve(MatchArgs A) {
                     t0 = lo;
                 }
                 uint32_t c1 = 0, c2 = 0;
-                if (t0 != PSL_KEY_INF) { c1 = V.gidx[t0 & 0xffff]; if (MODE == 1) c1 |= (uint32_t)V.kps[c1].octave << 12; }
-                if (t1 != PSL_KEY_INF) { c2 = V.gidx[t1 & 0xffff]; if (MODE == 1) c2 |= (uint32_t)V.kps[c2].octave << 12; }
+                if (t0 != PSL_KEY_INF) { c1 = posmap[t0 & 0xffff]; if (MODE == 1) c1 |= (uint32_t)V.kps[c1].octave << 12; }
+                if (t1 != PSL_KEY_INF) { c2 = posmap[t1 & 0xffff]; if (MODE == 1) c2 |= (uint32_t)V.kps[c2].octave << 12; }
                 const int pick = decide(t0, c1, t1, c2);
                 if (lane == 0 && s_choice[qi] != pick) { s_choice[qi] = pick; s_changed[f] = 1; }
             }
@@ -545,7 +567,7 @@ __global__ __launch_bounds__(BS) void k_window_resolve(MatchArgs A) {
     if (tid < PSL_HISTO) s_hist[tid] = 0;
     if (tid == 0) { s_ind[0] = s_ind[1] = s_ind[2] = -1; s_nm = 0; }
     __syncthreads();
-    const bool ori = MODE == 0 && A.check_ori;
+    const bool ori = (MODE == 0 || MODE == 2) && A.check_ori;
     if (ori) {
         const float factor = 1.0f / PSL_HISTO;
         for (int qi = tid; qi < nq; qi += BS) {
@@ -647,6 +669,7 @@ struct pslfe_frame {
     uint8_t* d_more = nullptr;   // [max_frames][cap]
     uint32_t* d_topk1 = nullptr; // [PSL_QMAX][PSL_TOPK] for the host-pointer entry points
     uint8_t* d_more1 = nullptr;
+    int* d_fidx = nullptr;       // [cap] the frame's FeatureVector (SearchByBoW, host-pointer entry point)
     float* d_depth = nullptr;    // [max_frames][cap] mvDepth (RGB-D post-processing)
     float* d_bounds = nullptr;   // [4] scratch for k_image_bounds
     std::vector<char> slot_set;
@@ -657,7 +680,8 @@ int pslfe_orb_internal_last(pslfe_orb* orb, const PslKeyPoint** kps, const uint8
 
 namespace {
 int host_search(pslfe_frame* f, int slot, const PslProjQuery* queries, const uint8_t* qdesc, int nq, const uint8_t* taken,
-                int mode, int check_ori, float nnratio, int32_t* match, int32_t* assigned, int* nmatches) {
+                int mode, int check_ori, float nnratio, int32_t* match, int32_t* assigned, int* nmatches, int th = PSL_TH_HIGH,
+                int no_stereo = 0, const int32_t* fidx = nullptr, int nfidx = 0) {
     PSL_REQUIRE(f && nmatches && (nq == 0 || (queries && qdesc && match)), PSLFE_E_INVALID, "search_by_projection: NULL argument");
     PSL_REQUIRE(slot >= 0 && slot < f->max_frames && f->slot_set[slot], PSLFE_E_STATE, "search_by_projection: slot %d not set", slot);
     PSL_REQUIRE(nq >= 0 && nq <= PSL_QMAX, PSLFE_E_INVALID, "search_by_projection: %d queries (max %d)", nq, PSL_QMAX);
@@ -671,8 +695,13 @@ int host_search(pslfe_frame* f, int slot, const PslProjQuery* queries, const uin
     PSL_HIP(hipMemcpyAsync(&m, f->S.meta + slot, sizeof(m), hipMemcpyDeviceToHost, st));
     PSL_HIP(hipStreamSynchronize(st));
     if (taken) PSL_HIP(hipMemcpyAsync(f->d_taken, taken, (size_t)m.n, hipMemcpyHostToDevice, st));
+    if (fidx) {  // the frame's FeatureVector: staged in the "assigned" scratch's sibling buffer
+        PSL_REQUIRE(nfidx >= 0 && nfidx <= f->cap, PSLFE_E_CAPACITY, "search_by_bow: %d feature-vector entries, capacity %d", nfidx, f->cap);
+        if (nfidx) PSL_HIP(hipMemcpyAsync(f->d_fidx, fidx, (size_t)nfidx * sizeof(int), hipMemcpyHostToDevice, st));
+    }
     MatchArgs A;
     A.S = f->S;
+    A.th = th; A.no_stereo = no_stereo; A.fidx = fidx ? f->d_fidx : nullptr;
     // host calls address exactly one slot; scratch arrays are indexed as "pair 0"
     A.slot0 = slot; A.q = f->d_q; A.qdesc = f->d_qdesc; A.nq_arr = nullptr; A.nq_single = nq; A.qstride = PSL_QMAX;
     A.taken = taken ? f->d_taken : nullptr; A.check_ori = check_ori; A.nnratio = nnratio;
@@ -682,7 +711,8 @@ int host_search(pslfe_frame* f, int slot, const PslProjQuery* queries, const uin
         PSL_STAGE_BEGIN(f->ctx, "match.window");
         k_window_eval<<<dim3((nq + 3) / 4, 1), 256, 0, st>>>(A);
         if (mode == 0) k_window_resolve<0, PSL_QMAX, 1024><<<1, 1024, 0, st>>>(A);
-        else k_window_resolve<1, PSL_QMAX, 1024><<<1, 1024, 0, st>>>(A);
+        else if (mode == 1) k_window_resolve<1, PSL_QMAX, 1024><<<1, 1024, 0, st>>>(A);
+        else k_window_resolve<2, PSL_QMAX, 1024><<<1, 1024, 0, st>>>(A);
         PSL_STAGE_END(f->ctx, "match.window");
     }
     PSL_HIP(hipGetLastError());
@@ -726,6 +756,7 @@ int pslfe_frame_create(pslfe_ctx* ctx, int max_keypoints, int max_frames, pslfe_
     A((void**)&f->d_more, F * K);
     A((void**)&f->d_topk1, (size_t)PSL_QMAX * PSL_TOPK * sizeof(uint32_t));
     A((void**)&f->d_more1, PSL_QMAX);
+    A((void**)&f->d_fidx, K * sizeof(int));
     A((void**)&f->d_depth, F * K * sizeof(float));
     A((void**)&f->d_bounds, 4 * sizeof(float));
     if (e != hipSuccess) {
@@ -746,7 +777,7 @@ void pslfe_frame_destroy(pslfe_frame* f) {
     hipFree(f->S.gidx); hipFree(f->S.meta); hipFree(f->d_q); hipFree(f->d_qdesc); hipFree(f->d_taken);
     hipFree(f->d_match); hipFree(f->d_assigned); hipFree(f->d_nm);
     hipFree(f->d_topk); hipFree(f->d_more); hipFree(f->d_topk1); hipFree(f->d_more1);
-    hipFree(f->d_depth); hipFree(f->d_bounds);
+    hipFree(f->d_depth); hipFree(f->d_bounds); hipFree(f->d_fidx);
     delete f;
 }
 
@@ -919,6 +950,36 @@ int pslfe_orb_search_by_projection_map(pslfe_frame* cur, int slot, const PslProj
     return host_search(cur, slot, queries, qdesc, nq, taken, 1, 0, nnratio, match, assigned, nmatches);
 }
 
+int pslfe_orb_search_by_projection_kf(pslfe_frame* cur, int slot, const PslProjQuery* queries, const uint8_t* qdesc, int nq,
+                                      const uint8_t* taken, int orb_dist, int check_orientation, int32_t* match, int32_t* assigned,
+                                      int* nmatches) {
+    PSL_REQUIRE(orb_dist >= 0 && orb_dist <= 256, PSLFE_E_INVALID, "pslfe_orb_search_by_projection_kf: ORBdist %d", orb_dist);
+    // every match occupies its keypoint (CurrentFrame.mvpMapPoints[bestIdx2] = pMP, :1566), so `blocks` is forced to 1
+    std::vector<PslProjQuery> q(queries, queries + (nq > 0 && queries ? nq : 0));
+    for (auto& e : q) e.blocks = 1;
+    return host_search(cur, slot, q.data(), qdesc, nq, taken, 0, check_orientation, 0.f, match, assigned, nmatches, orb_dist, 1);
+}
+
+int pslfe_orb_search_by_bow(pslfe_frame* f, int slot, const int32_t* fidx, int nfidx, const PslBowQuery* queries, const uint8_t* qdesc,
+                            int nq, float nnratio, int check_orientation, int32_t* match, int32_t* assigned, int* nmatches) {
+    PSL_REQUIRE(f && (nq == 0 || queries) && (nfidx == 0 || fidx), PSLFE_E_INVALID, "pslfe_orb_search_by_bow: NULL argument");
+    std::vector<PslProjQuery> q((size_t)(nq > 0 ? nq : 0));
+    for (int i = 0; i < nq; ++i) {
+        PSL_REQUIRE(queries[i].start >= 0 && queries[i].len >= 0 && queries[i].start + queries[i].len <= nfidx, PSLFE_E_INVALID,
+                    "pslfe_orb_search_by_bow: query %d refers to entries %d..%d of %d", i, queries[i].start, queries[i].start + queries[i].len, nfidx);
+        PslProjQuery e;
+        memset(&e, 0, sizeof(e));
+        e.min_level = queries[i].start; e.max_level = queries[i].len;  // the run, see MatchArgs::fidx
+        e.angle = queries[i].angle;
+        e.blocks = 1;  // vpMapPointMatches[bestIdxF] = pMP occupies the frame feature (:233)
+        q[i] = e;
+    }
+    for (int i = 0; i < nfidx; ++i)
+        PSL_REQUIRE(fidx[i] >= 0 && fidx[i] < f->cap, PSLFE_E_INVALID, "pslfe_orb_search_by_bow: feature index %d out of range", fidx[i]);
+    return host_search(f, slot, q.data(), qdesc, nq, nullptr, 2, check_orientation, nnratio, match, assigned, nmatches, 50 /* TH_LOW :38 */, 1,
+                       fidx, nfidx);
+}
+
 int pslfe_orb_search_by_projection_last_device(pslfe_frame* cur, int slot0, int npairs, const PslProjQuery* d_queries,
                                                const uint8_t* d_qdesc, const int32_t* d_nq, int qstride, int check_orientation,
                                                int32_t* d_match, int32_t* d_nmatches) {
@@ -931,6 +992,7 @@ int pslfe_orb_search_by_projection_last_device(pslfe_frame* cur, int slot0, int 
     MatchArgs A;
     A.S = cur->S; A.slot0 = slot0; A.q = d_queries; A.qdesc = d_qdesc; A.nq_arr = d_nq; A.nq_single = 0; A.qstride = qstride;
     A.taken = nullptr; A.check_ori = check_orientation; A.nnratio = 0.f; A.match = d_match; A.assigned = nullptr; A.nmatches = d_nmatches;
+    A.th = PSL_TH_HIGH; A.no_stereo = 0; A.fidx = nullptr;
     PSL_REQUIRE(qstride <= cur->cap && npairs <= cur->max_frames, PSLFE_E_CAPACITY, "search_by_projection_last_device: qstride %d > capacity %d", qstride, cur->cap);
     A.topk = cur->d_topk; A.more = cur->d_more;
     {

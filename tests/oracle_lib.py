@@ -416,3 +416,31 @@ def glibc_rand(seed, n):
     L.pso_glibc_rand.argtypes = [C.c_uint32, C.c_int, C.c_void_p]
     L.pso_glibc_rand(seed, n, _p(out))
     return out
+
+
+def search_by_projection_kf(kps, desc, bounds, queries, qdesc, taken, orb_dist, check_ori):
+    L = load()
+    kps = np.ascontiguousarray(kps, KEYPOINT_DTYPE); desc = np.ascontiguousarray(desc, np.uint8)
+    queries = np.ascontiguousarray(queries, PROJQUERY_DTYPE); qdesc = np.ascontiguousarray(qdesc, np.uint8)
+    n, nq = len(kps), len(queries)
+    tk = None if taken is None else np.ascontiguousarray(taken, np.uint8)
+    match = np.full(max(nq, 1), -1, np.int32); assigned = np.full(max(n, 1), -1, np.int32)
+    L.pso_search_by_projection_kf.argtypes = [C.c_void_p, C.c_void_p, C.c_int] + [C.c_float] * 4 + [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                                                                                 C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    nm = L.pso_search_by_projection_kf(_p(kps), _p(desc), n, *bounds, _p(queries), _p(qdesc), nq, _p(tk) if tk is not None else None,
+                                       int(orb_dist), int(check_ori), _p(match), _p(assigned))
+    return nm, match[:nq], assigned[:n]
+
+
+def search_by_bow(fdesc, fangle, fidx, runs, qdesc, qangle, nnratio, check_ori):
+    L = load()
+    fdesc = np.ascontiguousarray(fdesc, np.uint8); fangle = np.ascontiguousarray(fangle, np.float32)
+    fidx = np.ascontiguousarray(fidx, np.int32); runs = np.ascontiguousarray(runs, np.int32).reshape(-1, 2)
+    qdesc = np.ascontiguousarray(qdesc, np.uint8); qangle = np.ascontiguousarray(qangle, np.float32)
+    nf, nq = len(fangle), len(runs)
+    match = np.full(max(nq, 1), -1, np.int32); assigned = np.full(max(nf, 1), -1, np.int32)
+    L.pso_search_by_bow.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_int,
+                                    C.c_void_p, C.c_void_p]
+    nm = L.pso_search_by_bow(_p(fdesc), _p(fangle), nf, _p(fidx), _p(runs), _p(qdesc), _p(qangle), nq, float(nnratio), int(check_ori),
+                             _p(match), _p(assigned))
+    return nm, match[:nq], assigned[:nf]

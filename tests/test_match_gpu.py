@@ -193,3 +193,77 @@ def test_hip_reproduces_committed_match_golden():
     idx, dist = P.hamming_knn2(g["qdesc"][:200], g["d1"][:200])
     np.testing.assert_array_equal(idx, g["knn_idx"])
     np.testing.assert_array_equal(dist, g["knn_dist"])
+
+
+# ---- SearchByProjection(cur, KF) and SearchByBoW(KF, F) ----------------------------------------
+@pytest.mark.parametrize("orb_dist", [100, 64])
+@pytest.mark.parametrize("check_ori", [True, False])
+def test_search_by_projection_kf(orb_dist, check_ori):
+    import psl_slam_amd as P
+    import oracle_lib
+    ((k0, d0), (k1, d1)), _ = _frames()
+    rng = np.random.default_rng(17)
+    q, qd = make_queries(k0, d0, rng, th=10.0, jitter=3.0)
+    taken = (rng.random(len(k1)) < 0.2).astype(np.uint8)  # keypoints that already hold a map point
+    g = P.FrameGrid(2048, 1)
+    g.set(0, k1, d1, BOUNDS, uright=rng.uniform(1, 600, len(k1)).astype(np.float32))  # mvuRight must not gate this variant
+    nm, match, assigned = P.ORBmatcher(0.9, check_ori).SearchByProjectionKF(g, 0, q, qd, taken, ORBdist=orb_dist)
+    rnm, rmatch, rassigned = oracle_lib.search_by_projection_kf(k1, d1, BOUNDS, q, qd, taken, orb_dist, check_ori)
+    assert nm == rnm and nm > 100
+    np.testing.assert_array_equal(match, rmatch)
+    np.testing.assert_array_equal(assigned, rassigned)
+    assert not taken[match[match >= 0]].any()
+
+
+def _feature_vector(desc, nnodes):
+    """stand-in for DBoW2's FeatureVector: node = a hash of the descriptor; indices ascending inside a node"""
+    node = (desc[:, 0].astype(np.int32) * 7 + desc[:, 5]) % nnodes
+    return {int(nd): np.nonzero(node == nd)[0].astype(np.int32) for nd in np.unique(node)}
+
+
+def _bow_inputs(dkf, akf, valid, fv_kf, fv_f):
+    fidx, start = [], {}
+    for nd in sorted(fv_f):
+        start[nd] = (len(fidx), len(fv_f[nd]))
+        fidx.extend(fv_f[nd].tolist())
+    runs, qa, qd = [], [], []
+    for nd in sorted(fv_kf):          # common nodes ascending, vIndicesKF order, features without a good map point dropped
+        if nd not in start:
+            continue
+        for i in fv_kf[nd]:
+            if valid[i]:
+                runs.append(start[nd]); qa.append(akf[i]); qd.append(dkf[i])
+    return (np.array(fidx, np.int32), np.array(runs, np.int32).reshape(-1, 2), np.array(qa, np.float32),
+            np.array(qd, np.uint8).reshape(-1, 32))
+
+
+@pytest.mark.parametrize("nnodes,ratio", [(40, 0.7), (6, 0.9), (400, 0.75)])
+@pytest.mark.parametrize("check_ori", [True, False])
+def test_search_by_bow(nnodes, ratio, check_ori):
+    """few nodes -> long runs (more than the 8 cached candidates: the rescan path), many nodes -> short and empty runs"""
+    import psl_slam_amd as P
+    import oracle_lib
+    ((k0, d0), (k1, d1)), _ = _frames()
+    rng = np.random.default_rng(23)
+    valid = rng.random(len(k0)) < 0.8
+    fidx, runs, qa, qd = _bow_inputs(d0, k0["angle"], valid, _feature_vector(d0, nnodes), _feature_vector(d1, nnodes))
+    g = P.FrameGrid(2048, 1)
+    g.set(0, k1, d1, BOUNDS)
+    nm, match, assigned = P.ORBmatcher(ratio, check_ori).SearchByBoW(g, 0, fidx, runs, qa, qd)
+    rnm, rmatch, rassigned = oracle_lib.search_by_bow(d1, k1["angle"], fidx, runs, qd, qa, ratio, check_ori)
+    assert nm == rnm
+    np.testing.assert_array_equal(match, rmatch)
+    np.testing.assert_array_equal(assigned, rassigned)
+    if nnodes <= 40:
+        assert nm > 20
+
+
+def test_search_by_bow_empty_and_bad_input():
+    import psl_slam_amd as P
+    ((k0, d0), (k1, d1)), _ = _frames()
+    g = P.FrameGrid(2048, 1)
+    g.set(0, k1, d1, BOUNDS)
+    nm, match, assigned = P.ORBmatcher(0.7, True).SearchByBoW(g, 0, np.zeros(0, np.int32), np.zeros((0, 2), np.int32), [], np.zeros((0, 32), np.uint8))
+    assert nm == 0 and len(match) == 0
+    with pytest.raises(P.PslfeError):  # a run that leaves the feature vector
+        P.ORBmatcher(0.7, True).SearchByBoW(g, 0, np.arange(10, dtype=np.int32), [(5, 10)], [0.0], d0[:1])

@@ -206,3 +206,109 @@ def test_image_bounds_and_zero_distortion_identity():
     assert un.tobytes() == kps.tobytes()
     np.testing.assert_array_equal(dep, [-1, 1.5, -1])
     np.testing.assert_array_equal(ur, np.array([-1, np.float32(300.2) - np.float32(40.0) / np.float32(1.5), -1], np.float32))
+
+
+# ---- a18: SearchByBoW / SearchByProjection(cur, KF) against plain-Python restatements -----------------------------
+def _py_three_maxima(h):
+    m1 = m2 = m3 = 0
+    i1 = i2 = i3 = -1
+    for i, s in enumerate(h):
+        if s > m1:
+            m3, m2, m1, i3, i2, i1 = m2, m1, s, i2, i1, i
+        elif s > m2:
+            m3, m2, i3, i2 = m2, s, i2, i
+        elif s > m3:
+            m3, i3 = s, i
+    if m2 < 0.1 * m1:
+        i2 = i3 = -1
+    elif m3 < 0.1 * m1:
+        i3 = -1
+    return i1, i2, i3
+
+
+def _py_bow(fdesc, fangle, fidx, runs, qdesc, qangle, ratio, ori):
+    owner = {}
+    match = [-1] * len(runs)
+    hist = [[] for _ in range(30)]
+    for i, (s, ln) in enumerate(runs):
+        b1, b2, bi = 256, 256, -1
+        for p in range(s, s + ln):
+            f = int(fidx[p])
+            if f in owner:
+                continue
+            d = popcount_dist(qdesc[i], fdesc[f])
+            if d < b1:
+                b2, b1, bi = b1, d, f
+            elif d < b2:
+                b2 = d
+        if b1 <= 50 and np.float32(b1) < np.float32(ratio) * np.float32(b2):
+            owner[bi] = i
+            match[i] = bi
+            if ori:
+                rot = np.float32(qangle[i]) - np.float32(fangle[bi])
+                if rot < 0:
+                    rot = np.float32(rot + np.float32(360.0))
+                b = int(np.round(np.float32(rot * np.float32(1.0 / 30))))  # round half away == np.round only off exact .5: avoided below
+                hist[0 if b == 30 else b].append((i, bi))
+    if ori:
+        keep = _py_three_maxima([len(h) for h in hist])
+        for b, h in enumerate(hist):
+            if b not in keep:
+                for i, f in h:
+                    match[i] = -1
+                    del owner[f]
+    return sum(m >= 0 for m in match), np.array(match, np.int32), owner
+
+
+def test_search_by_bow_against_plain_python():
+    rng = np.random.default_rng(4)
+    nf, nkf, nnodes = 300, 280, 12
+    base = rng.integers(0, 256, (nf, 32), dtype=np.uint8)
+    fdesc = base.copy()
+    qsrc = base[rng.permutation(nf)[:nkf]].copy()
+    flip = rng.integers(0, 32, nkf)
+    qsrc[np.arange(nkf), flip] ^= rng.integers(1, 64, nkf).astype(np.uint8)  # near-duplicates: matches with small distances
+    fangle = rng.uniform(0, 360, nf).astype(np.float32) + np.float32(0.013)
+    qangle_all = rng.uniform(0, 360, nkf).astype(np.float32)
+    fnode = fdesc[:, 1] % nnodes
+    qnode = qsrc[:, 1] % nnodes
+    fidx, start = [], {}
+    for nd in range(nnodes):
+        ids = np.nonzero(fnode == nd)[0]
+        start[nd] = (len(fidx), len(ids))
+        fidx.extend(ids.tolist())
+    runs, qd, qa = [], [], []
+    for nd in range(nnodes):
+        for i in np.nonzero(qnode == nd)[0]:
+            runs.append(start[nd]); qd.append(qsrc[i]); qa.append(qangle_all[i])
+    runs = np.array(runs, np.int32); qd = np.array(qd, np.uint8); qa = np.array(qa, np.float32)
+    for ori in (False, True):
+        nm, match, assigned = oracle_lib.search_by_bow(fdesc, fangle, np.array(fidx, np.int32), runs, qd, qa, 0.8, ori)
+        pnm, pmatch, powner = _py_bow(fdesc, fangle, fidx, runs, qd, qa, 0.8, ori)
+        assert nm == pnm and nm > 30
+        np.testing.assert_array_equal(match, pmatch)
+        for f, i in powner.items():
+            assert assigned[f] == i
+        assert (assigned >= 0).sum() == len(powner)
+
+
+def test_search_by_projection_kf_semantics_small():
+    """two queries want the same keypoint: the first takes it, the second falls back to its next candidate or to nothing;
+    an occupied keypoint is never used; the distance gate is ORBdist."""
+    kps = np.zeros(3, oracle_lib.KEYPOINT_DTYPE)
+    kps["x"], kps["y"] = [100, 104, 300], [100, 100, 300]
+    desc = np.zeros((3, 32), np.uint8)
+    desc[1, 0] = 0x0F  # 4 bits from keypoint 0
+    desc[2, :] = 0xFF
+    q = np.zeros(3, oracle_lib.PROJQUERY_DTYPE)
+    q["u"], q["v"], q["radius"] = [101, 102, 300], [100, 100, 300], 20
+    q["min_level"], q["max_level"] = -1, -1
+    qd = np.zeros((3, 32), np.uint8)
+    qd[2, :4] = 0x00
+    qd[2, 4:] = 0xFF  # 32 bits from keypoint 2
+    nm, match, assigned = oracle_lib.search_by_projection_kf(kps, desc, BOUNDS, q, qd, None, 100, False)
+    assert nm == 3 and list(match) == [0, 1, 2] and list(assigned) == [0, 1, 2]
+    nm, match, _ = oracle_lib.search_by_projection_kf(kps, desc, BOUNDS, q, qd, None, 3, False)  # ORBdist 3: 4 and 32 bits fail
+    assert nm == 1 and list(match) == [0, -1, -1]
+    nm, match, _ = oracle_lib.search_by_projection_kf(kps, desc, BOUNDS, q, qd, np.array([1, 0, 0], np.uint8), 100, False)
+    assert list(match) == [1, -1, 2]  # keypoint 0 is occupied: query 0 takes 1, query 1 finds nothing free
