@@ -147,6 +147,28 @@ public:
               "pslfe_orb_search_by_projection_map");
         return nm;
     }
+    // SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th, ORBdist), src/ORBmatcher.cc:1472 (relocalisation): the caller has
+    // projected the keyframe's map points; taken[c] != 0 <=> CurrentFrame.mvpMapPoints[c] != NULL.
+    int SearchByProjectionKF(FrameGrid& cur, int slot, const std::vector<PslProjQuery>& queries, const std::vector<uint8_t>& qdesc,
+                             const uint8_t* taken, int ORBdist, std::vector<int32_t>& match, std::vector<int32_t>* assigned = nullptr) {
+        match.assign(queries.size(), -1);
+        int nm = 0;
+        check(pslfe_orb_search_by_projection_kf(cur.get(), slot, queries.data(), qdesc.data(), (int)queries.size(), taken, ORBdist,
+                                                mbCheckOrientation ? 1 : 0, match.data(), assigned ? assigned->data() : nullptr, &nm),
+              "pslfe_orb_search_by_projection_kf");
+        return nm;
+    }
+    // SearchByBoW(pKF, F, vpMapPointMatches), src/ORBmatcher.cc:159, on host-side DBoW2 FeatureVectors: fidx = F.mFeatVec flattened
+    // in node order; one query (node run of fidx, angle) + descriptor per keyframe feature, in the reference's iteration order.
+    int SearchByBoW(FrameGrid& frame, int slot, const std::vector<int32_t>& fidx, const std::vector<PslBowQuery>& queries,
+                    const std::vector<uint8_t>& qdesc, std::vector<int32_t>& match, std::vector<int32_t>* assigned = nullptr) {
+        match.assign(queries.size(), -1);
+        int nm = 0;
+        check(pslfe_orb_search_by_bow(frame.get(), slot, fidx.data(), (int)fidx.size(), queries.data(), qdesc.data(), (int)queries.size(),
+                                      mfNNratio, mbCheckOrientation ? 1 : 0, match.data(), assigned ? assigned->data() : nullptr, &nm),
+              "pslfe_orb_search_by_bow");
+        return nm;
+    }
     // DescriptorDistance, src/ORBmatcher.cc:1647-1663 (host helper, same SWAR popcount)
     static int DescriptorDistance(const uint8_t* a, const uint8_t* b) {
         const uint32_t* pa = reinterpret_cast<const uint32_t*>(a);
