@@ -398,6 +398,32 @@ int pslfe_line_search_by_projection(pslfe_ctx* ctx, const PslKeyLine* kls, const
                                     float nnratio, int32_t* match, int32_t* assigned, int* nmatches, int32_t* grid_start,
                                     int32_t* grid_idx, int grid_cap, int* grid_n);
 
+/* ---- Frame::ComputeBoW ------------------------------------------------------------- */
+typedef struct pslfe_vocab pslfe_vocab;
+/* The DBoW2 vocabulary (ORBvoc.txt: k = 10, L = 6, TF_IDF weighting, L1_NORM scoring) as flat arrays, uploaded once:
+ * node i has children child_ids[child_begin[i] .. + child_count[i]) in the order of Node::children
+ * (Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:297-329), a 32-byte descriptor, its weight and word id; a node without
+ * children is a leaf (a word); node 0 is the root; L = depth of the tree (m_L). */
+int pslfe_vocab_create(pslfe_ctx* ctx, int nnodes, const int32_t* child_begin, const int32_t* child_count,
+                       const int32_t* child_ids, int nchild, const uint8_t* node_desc, const double* node_weight,
+                       const int32_t* node_word, int L, pslfe_vocab** out);
+void pslfe_vocab_destroy(pslfe_vocab* v);
+/* == Frame::ComputeBoW src/Frame.cc:1053-1060 -> mpORBvocabulary->transform(descriptors, mBowVec, mFeatVec, levelsup = 4)
+ *    (TemplatedVocabulary.h:1124-1195, 1218-1260).  desc: n x 32.  Per feature (any pointer may be NULL): word id,
+ *    weight (features with weight <= 0 are dropped, as the reference drops stopped words) and the node at level
+ *    L - levelsup.  mBowVec: nbow ascending (bow_id, bow_val) pairs, L1-normalised.  mFeatVec: nfv ascending node ids
+ *    fv_node, node g owning fv_idx[fv_start[g] .. fv_start[g+1]) (feature indices ascending) - exactly the `fidx` /
+ *    runs that pslfe_orb_search_by_bow takes. */
+int pslfe_compute_bow(pslfe_vocab* v, const uint8_t* desc, int n, int levelsup, int32_t* f_word, double* f_weight,
+                      int32_t* f_nid, int32_t* bow_id, double* bow_val, int* nbow, int32_t* fv_node, int32_t* fv_start,
+                      int32_t* fv_idx, int* nfv);
+/* Same for nframes frames in HBM: descriptors [nframes][stride][32], counts [nframes]; outputs [nframes][stride]
+ * (bow_start / fv_start: [nframes][stride + 1]; bow_start is scratch), counts [nframes].  Asynchronous. */
+int pslfe_compute_bow_device(pslfe_vocab* v, const uint8_t* d_desc, const int32_t* d_counts, int nframes, int stride,
+                             int levelsup, int32_t* d_fword, double* d_fweight, int32_t* d_fnid, int32_t* d_bow_id,
+                             double* d_bow_val, int32_t* d_bow_start, int32_t* d_nbow, int32_t* d_fv_node,
+                             int32_t* d_fv_start, int32_t* d_fv_idx, int32_t* d_nfv);
+
 /* ---- RGB-D line glue of the Frame constructor ------------------------------ */
 typedef struct pslfe_glue pslfe_glue;
 /* Buffers for up to max_batch frames of max_lines keylines and max_fans LIL rows each. */

@@ -111,6 +111,12 @@ int pso_search_by_projection_kf(const PsoKeyPoint* kps, const uint8_t* desc, int
 int pso_search_by_bow(const uint8_t* fdesc, const float* fangle, int nf, const int32_t* fidx, const int32_t* run, const uint8_t* qdesc,
                       const float* qangle, int nq, float nnratio, int checkOri, int* match, int* assigned);
 
+/* Frame::ComputeBoW = DBoW2 transform on a flat vocabulary (bow_oracle.cpp) */
+int pso_compute_bow(const int32_t* child_begin, const int32_t* child_count, const int32_t* child_ids, const uint8_t* node_desc,
+                    const double* node_weight, const int32_t* node_word, int L, int levelsup, const uint8_t* desc, int n, int32_t* f_word,
+                    double* f_weight, int32_t* f_nid, int32_t* bow_id, double* bow_val, int32_t* fv_node, int32_t* fv_start, int32_t* fv_idx,
+                    int* n_fv);
+
 /* RGB-D line glue of the Frame constructor (glue_oracle.cpp) */
 void pso_line_good(const PsoKeyLine* kls, int n, const float* depth, int cols, int rows, int dstride, const float* cam, uint32_t seed,
                    double* lines3d, float* lineEq);

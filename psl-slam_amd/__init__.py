@@ -782,3 +782,51 @@ class FrameGlue:
             self.close()
         except Exception:
             pass
+
+
+class ORBVocabulary:
+    """== DBoW2 ORBVocabulary as far as Frame::ComputeBoW needs it: transform(descriptors, BowVector, FeatureVector, levelsup).
+    Built from flat arrays (the host keeps parsing ORBvoc.txt): children[i] = list of child node ids of node i (node 0 = root),
+    node_desc (nnodes x 32 u8), node_weight (f64), node_word (i32), L = depth."""
+
+    def __init__(self, children, node_desc, node_weight, node_word, L, ctx=None):
+        self.ctx = ctx or default_context()
+        nn = len(children)
+        cb = np.zeros(nn, np.int32)
+        cc = np.array([len(c) for c in children], np.int32)
+        cb[1:] = np.cumsum(cc)[:-1]
+        ids = np.array([x for c in children for x in c], np.int32)
+        self.arrays = (cb, cc, ids, np.ascontiguousarray(node_desc, np.uint8), np.ascontiguousarray(node_weight, np.float64),
+                       np.ascontiguousarray(node_word, np.int32), int(L))
+        self._h = C.c_void_p()
+        _check(lib().pslfe_vocab_create(self.ctx._h, C.c_int(nn), _ptr(cb), _ptr(cc), _ptr(ids), C.c_int(len(ids)), _ptr(self.arrays[3]),
+                                        _ptr(self.arrays[4]), _ptr(self.arrays[5]), C.c_int(L), C.byref(self._h)), "pslfe_vocab_create")
+
+    def transform(self, desc, levelsup=4):
+        """-> dict(word, weight, nid per feature; bow_id, bow_val; fv_node, fv_start, fv_idx)"""
+        desc = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+        n = len(desc)
+        m = max(n, 1)
+        o = dict(word=np.zeros(m, np.int32), weight=np.zeros(m, np.float64), nid=np.zeros(m, np.int32), bow_id=np.zeros(m, np.int32),
+                 bow_val=np.zeros(m, np.float64), fv_node=np.zeros(m, np.int32), fv_start=np.zeros(m + 1, np.int32), fv_idx=np.zeros(m, np.int32))
+        nb, nf = C.c_int(), C.c_int()
+        _check(lib().pslfe_compute_bow(self._h, _ptr(desc), C.c_int(n), C.c_int(levelsup), _ptr(o["word"]), _ptr(o["weight"]), _ptr(o["nid"]),
+                                       _ptr(o["bow_id"]), _ptr(o["bow_val"]), C.byref(nb), _ptr(o["fv_node"]), _ptr(o["fv_start"]),
+                                       _ptr(o["fv_idx"]), C.byref(nf)), "pslfe_compute_bow")
+        for k in ("word", "weight", "nid"):
+            o[k] = o[k][:n]
+        o["bow_id"], o["bow_val"] = o["bow_id"][:nb.value], o["bow_val"][:nb.value]
+        o["fv_node"], o["fv_start"] = o["fv_node"][:nf.value], o["fv_start"][:nf.value + 1]
+        o["fv_idx"] = o["fv_idx"][:int(o["fv_start"][nf.value])] if nf.value else o["fv_idx"][:0]
+        return o
+
+    def close(self):
+        if self._h:
+            lib().pslfe_vocab_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

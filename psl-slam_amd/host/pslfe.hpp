@@ -329,5 +329,40 @@ private:
     int maxFans_;
 };
 
+// DBoW2 ORBVocabulary as far as Frame::ComputeBoW needs it (src/Frame.cc:1053-1060): the tree as flat arrays, transform on the device.
+class ORBVocabulary {
+public:
+    struct Result {
+        std::vector<int32_t> word, nid;        // per feature
+        std::vector<double> weight;
+        std::vector<int32_t> bowId;            // mBowVec, ascending
+        std::vector<double> bowVal;
+        std::vector<int32_t> fvNode, fvStart, fvIdx;  // mFeatVec: node g owns fvIdx[fvStart[g] .. fvStart[g+1])
+    };
+    // node i: children childIds[childBegin[i] .. + childCount[i]) in Node::children order; node 0 = root; L = m_L
+    ORBVocabulary(Context& ctx, const std::vector<int32_t>& childBegin, const std::vector<int32_t>& childCount, const std::vector<int32_t>& childIds,
+                  const std::vector<uint8_t>& nodeDesc, const std::vector<double>& nodeWeight, const std::vector<int32_t>& nodeWord, int L) {
+        check(pslfe_vocab_create(ctx.get(), (int)childBegin.size(), childBegin.data(), childCount.data(), childIds.data(), (int)childIds.size(),
+                                 nodeDesc.data(), nodeWeight.data(), nodeWord.data(), L, &h_), "pslfe_vocab_create");
+    }
+    ~ORBVocabulary() { pslfe_vocab_destroy(h_); }
+    ORBVocabulary(const ORBVocabulary&) = delete;
+    ORBVocabulary& operator=(const ORBVocabulary&) = delete;
+    Result transform(const std::vector<uint8_t>& descriptors, int levelsup = 4) {
+        const int n = (int)descriptors.size() / 32;
+        Result r;
+        r.word.resize(n); r.nid.resize(n); r.weight.resize(n); r.bowId.resize(n); r.bowVal.resize(n);
+        r.fvNode.resize(n); r.fvStart.resize(n + 1); r.fvIdx.resize(n);
+        int nb = 0, nf = 0;
+        check(pslfe_compute_bow(h_, descriptors.data(), n, levelsup, r.word.data(), r.weight.data(), r.nid.data(), r.bowId.data(), r.bowVal.data(),
+                                &nb, r.fvNode.data(), r.fvStart.data(), r.fvIdx.data(), &nf), "pslfe_compute_bow");
+        r.bowId.resize(nb); r.bowVal.resize(nb); r.fvNode.resize(nf); r.fvStart.resize(nf + 1);
+        r.fvIdx.resize(nf ? r.fvStart[nf] : 0);
+        return r;
+    }
+private:
+    pslfe_vocab* h_ = nullptr;
+};
+
 }  // namespace pslfe
 #endif

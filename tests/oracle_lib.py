@@ -444,3 +444,27 @@ def search_by_bow(fdesc, fangle, fidx, runs, qdesc, qangle, nnratio, check_ori):
     nm = L.pso_search_by_bow(_p(fdesc), _p(fangle), nf, _p(fidx), _p(runs), _p(qdesc), _p(qangle), nq, float(nnratio), int(check_ori),
                              _p(match), _p(assigned))
     return nm, match[:nq], assigned[:nf]
+
+
+def compute_bow(children, node_desc, node_weight, node_word, L, desc, levelsup=4):
+    Lb = load()
+    nn = len(children)
+    cb = np.zeros(nn, np.int32)
+    cc = np.array([len(c) for c in children], np.int32)
+    cb[1:] = np.cumsum(cc)[:-1]
+    ids = np.array([x for c in children for x in c], np.int32)
+    nd = np.ascontiguousarray(node_desc, np.uint8); nw = np.ascontiguousarray(node_weight, np.float64); nwd = np.ascontiguousarray(node_word, np.int32)
+    desc = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+    n = len(desc); m = max(n, 1)
+    o = dict(word=np.zeros(m, np.int32), weight=np.zeros(m, np.float64), nid=np.zeros(m, np.int32), bow_id=np.zeros(m, np.int32),
+             bow_val=np.zeros(m, np.float64), fv_node=np.zeros(m, np.int32), fv_start=np.zeros(m + 1, np.int32), fv_idx=np.zeros(m, np.int32))
+    nf = C.c_int()
+    Lb.pso_compute_bow.argtypes = [C.c_void_p] * 6 + [C.c_int, C.c_int, C.c_void_p, C.c_int] + [C.c_void_p] * 9
+    nb = Lb.pso_compute_bow(_p(cb), _p(cc), _p(ids), _p(nd), _p(nw), _p(nwd), int(L), int(levelsup), _p(desc), n, _p(o["word"]), _p(o["weight"]),
+                            _p(o["nid"]), _p(o["bow_id"]), _p(o["bow_val"]), _p(o["fv_node"]), _p(o["fv_start"]), _p(o["fv_idx"]), C.byref(nf))
+    for k in ("word", "weight", "nid"):
+        o[k] = o[k][:n]
+    o["bow_id"], o["bow_val"] = o["bow_id"][:nb], o["bow_val"][:nb]
+    o["fv_node"], o["fv_start"] = o["fv_node"][:nf.value], o["fv_start"][:nf.value + 1]
+    o["fv_idx"] = o["fv_idx"][:int(o["fv_start"][nf.value])] if nf.value else o["fv_idx"][:0]
+    return o
