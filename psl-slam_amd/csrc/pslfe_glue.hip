@@ -362,7 +362,10 @@ __device__ __forceinline__ int psl_glibc_rand_lane0(GlueLds& S, int k) {  // lan
     return (int)(v >> 1);
 }
 
-__global__ __launch_bounds__(64, 4) void k_line_good(const PslKeyLine* __restrict__ kls, int kl_stride, const int32_t* __restrict__ nkl,
+#ifndef PSL_GOOD_WAVES
+#define PSL_GOOD_WAVES 4
+#endif
+__global__ __launch_bounds__(64, PSL_GOOD_WAVES) void k_line_good(const PslKeyLine* __restrict__ kls, int kl_stride, const int32_t* __restrict__ nkl,
                                                    int nkl_single, const float* __restrict__ depth, int cols, int rows, int dstride,
                                                    size_t dframe, PslCamera cam, uint32_t seed0, double* __restrict__ lines3d,
                                                    float* __restrict__ lineEq) {
