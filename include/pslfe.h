@@ -424,6 +424,70 @@ int pslfe_compute_bow_device(pslfe_vocab* v, const uint8_t* d_desc, const int32_
                              double* d_bow_val, int32_t* d_bow_start, int32_t* d_nbow, int32_t* d_fv_node,
                              int32_t* d_fv_start, int32_t* d_fv_idx, int32_t* d_nfv);
 
+/* ---- KeyFrame-rate matchers of LocalMapping / LoopClosing ------------------------------ */
+/* These run on other threads than Tracking in the reference (src/LocalMapping.cc:336, 580, 796-872,
+ * src/LoopClosing.cc:599, 245-330): give them their own pslfe_ctx (own stream) and one pslfe_kf handle per thread.  A frame
+ * slot they read must be complete (its owner's stream synchronised) when it belongs to another context.  All entry points
+ * take host pointers and return after the results have arrived. */
+typedef struct pslfe_kf pslfe_kf;
+int pslfe_kf_create(pslfe_ctx* ctx, pslfe_kf** out);
+void pslfe_kf_destroy(pslfe_kf* k);
+
+/* The candidate loop shared by ORBmatcher::Fuse(pKF, vpMapPoints, th) src/ORBmatcher.cc:825-966 (chi2 = 1: the
+ * reprojection gates :907-934, 7.8 with a right coordinate and 5.99 without), ORBmatcher::Fuse(pKF, Scw, vpPoints, th,
+ * vpReplacePoint) :968-1100 (chi2 = 0) and one direction of SearchBySim3 :1165-1232: KeyFrame::GetFeaturesInArea(u, v,
+ * radius) src/KeyFrame.cc:685-724 on the grid of slot `slot`, octaves max_level-1 .. max_level (max_level =
+ * nPredictedLevel; min_level, angle, blocks are ignored), the smallest DescriptorDistance, first visited on ties.
+ * The host projects (it owns the map points); a query with radius < 0 is one the reference dropped before the search.
+ * best_idx[i] = keypoint or -1, best_dist[i] = its distance or INT_MAX: the caller applies bestDist <= TH_LOW and
+ * mutates the map (:950-964).  inv_level_sigma2: pKF->mvInvLevelSigma2 (nlevels <= 16 entries; chi2 = 1 only). */
+int pslfe_kf_window_best(pslfe_kf* k, pslfe_frame* f, int slot, const PslProjQuery* queries, const uint8_t* qdesc, int nq,
+                         int chi2, const float* inv_level_sigma2, int nlevels, int32_t* best_idx, int32_t* best_dist);
+/* == ORBmatcher::SearchBySim3 src/ORBmatcher.cc:1102-1326 after the projections: q12[i1] = map point i1 of KF1 in KF2's
+ *    image (radius < 0: none / already matched / bad / a gate failed), qdesc1 its descriptor, n1 = N1; q21 / qdesc2 / n2
+ *    likewise.  Both directions, TH_HIGH, then the agreement check :1307-1323: match12[i1] = idx2 or -1. */
+int pslfe_kf_search_by_sim3(pslfe_kf* k, pslfe_frame* f1, int slot1, pslfe_frame* f2, int slot2, const PslProjQuery* q12,
+                            const uint8_t* qdesc1, int n1, const PslProjQuery* q21, const uint8_t* qdesc2, int n2,
+                            int32_t* match12, int* nfound);
+/* One feature of KF1 in ORBmatcher::SearchForTriangulation, in the reference's iteration order (common vocabulary nodes
+ * ascending, f1it->second order; features that have a map point and, under bOnlyStereo, those without a right coordinate
+ * are dropped by the caller, :699-711). */
+typedef struct PslTriQuery {
+    int32_t start, len; /* the run of KF2's flattened FeatureVector under the shared node */
+    float x, y, angle;  /* pKF1->mvKeysUn[idx1].pt, .angle                                  */
+    int32_t stereo;     /* pKF1->mvuRight[idx1] >= 0                                       */
+} PslTriQuery;
+/* == ORBmatcher::SearchForTriangulation src/ORBmatcher.cc:657-823 with CheckDistEpipolarLine :140-157.  Slot `slot2` of f2
+ *    holds KF2 (mvKeysUn, mvuRight, descriptors); fidx2: its FeatureVector flattened in node order; taken2[idx2] != 0 <=>
+ *    pKF2->GetMapPoint(idx2) != NULL; F12 row-major 3x3; (ex, ey) the epipole :664-671; scale_factors / level_sigma2 =
+ *    pKF2->mvScaleFactors / mvLevelSigma2.  TH_LOW = 50, the LAST candidate wins among equal distances (:738), vbMatched2
+ *    is never set by the reference (:686) so queries are independent; rotation histogram :764-775, :793-811.
+ *    match[i] = idx2 of query i or -1; *nmatches = the return value. */
+int pslfe_kf_search_for_triangulation(pslfe_kf* k, pslfe_frame* f2, int slot2, const int32_t* fidx2, int nfidx2,
+                                      const uint8_t* taken2, const PslTriQuery* queries, const uint8_t* qdesc, int nq,
+                                      const float* F12, float ex, float ey, int only_stereo, int check_orientation,
+                                      const float* scale_factors, const float* level_sigma2, int nlevels, int32_t* match,
+                                      int* nmatches);
+/* One projected map line of LSDmatcher::Fuse (add_src/LSDmatcher.cpp:885-931). */
+typedef struct PslLineFuseQuery {
+    float x1, y1, x2, y2; /* u1, v1, u2, v2                                 */
+    float radius;         /* th * mvScaleFactorsLine[level]; < 0: dropped   */
+    int32_t level;        /* nPredictedLevel                                */
+} PslLineFuseQuery;
+/* == the search of LSDmatcher::Fuse add_src/LSDmatcher.cpp:933-958: KeyFrame::GetLinesInArea(u1, v1, u2, v2, radius,
+ *    TH = 0.998) src/KeyFrame.cc:857-891 over kls = pKF->mvKeyLines, octaves level-1 .. level, smallest distance to
+ *    desc row idx, first on ties; best_dist = 256 when none.  `desc` (ndesc rows) is the matrix the caller reads rows
+ *    from: the reference indexes pKF->mDescriptors (the ORB matrix) with the line index at :945; a line without a row is
+ *    skipped. */
+int pslfe_kf_line_fuse_best(pslfe_kf* k, const PslKeyLine* kls, int n, const uint8_t* desc, int ndesc,
+                            const PslLineFuseQuery* queries, const uint8_t* qdesc, int nq, int32_t* best_idx,
+                            int32_t* best_dist);
+/* == MapPoint::ComputeDistinctiveDescriptors src/MapPoint.cc:242-304 and MapLine::ComputeDistinctiveDescriptors
+ *    add_src/MapLine.cpp:250-310 for npts map points / lines at once: the observed descriptors of point p are rows
+ *    offsets[p] .. offsets[p+1] of desc (at most 1024 per point); best[p] = the row (relative to offsets[p]) with the
+ *    least median Hamming distance to the others (median = sorted[0.5*(N-1)], first on ties), -1 for an empty run. */
+int pslfe_kf_distinctive_descriptors(pslfe_kf* k, const uint8_t* desc, const int32_t* offsets, int npts, int32_t* best);
+
 /* ---- RGB-D line glue of the Frame constructor ------------------------------ */
 typedef struct pslfe_glue pslfe_glue;
 /* Buffers for up to max_batch frames of max_lines keylines and max_fans LIL rows each. */

@@ -32,6 +32,19 @@ typedef struct PsoProjQuery {
     int32_t blocks;
 } PsoProjQuery;
 
+/* one feature of KF1 in ORBmatcher::SearchForTriangulation (src/ORBmatcher.cc:693-775) */
+typedef struct PsoTriQuery {
+    int32_t start, len;  /* the run of KF2's flattened FeatureVector under the shared node */
+    float x, y, angle;   /* pKF1->mvKeysUn[idx1] */
+    int32_t stereo;      /* pKF1->mvuRight[idx1] >= 0 */
+} PsoTriQuery;
+
+/* one projected map line of LSDmatcher::Fuse (add_src/LSDmatcher.cpp:885-931) */
+typedef struct PsoLineFuseQuery {
+    float x1, y1, x2, y2, radius;  /* radius < 0: dropped by a gate before the search */
+    int32_t level;                 /* nPredictedLevel */
+} PsoLineFuseQuery;
+
 typedef struct PsoLineQuery {
     float x1, y1, x2, y2;   /* mTrackProjX1.. : projected end points */
     float radius, th_cos;   /* r and TH of GetFeaturesInAreaForLine */
@@ -74,6 +87,17 @@ int pso_search_by_projection_map(const PsoKeyPoint* kps, const uint8_t* desc, co
                                  float minY, float maxX, float maxY, const PsoProjQuery* q, const uint8_t* qdesc, int nq,
                                  const uint8_t* taken, float nnratio, int* match, int* assigned);
 void pso_hamming_knn2(const uint8_t* q, int nq, const uint8_t* t, int nt, int* idx, int* dist);
+void pso_window_best(const PsoKeyPoint* kps, const uint8_t* desc, const float* uright, int n, const float* bounds, const PsoProjQuery* q,
+                     const uint8_t* qdesc, int nq, int chi2, const float* invSigma2, int* best_idx, int* best_dist);
+int pso_search_by_sim3(const PsoKeyPoint* kps1, const uint8_t* desc1, int n1, const float* bounds1, const PsoKeyPoint* kps2,
+                       const uint8_t* desc2, int n2, const float* bounds2, const PsoProjQuery* q12, const uint8_t* qdesc1,
+                       const PsoProjQuery* q21, const uint8_t* qdesc2, int* match12);
+int pso_search_for_triangulation(const PsoKeyPoint* kps2, const uint8_t* desc2, const float* uright2, const uint8_t* taken2,
+                                 const int32_t* fidx2, const PsoTriQuery* q, const uint8_t* qdesc, int nq, const float* F12, float ex,
+                                 float ey, int bOnlyStereo, int checkOri, const float* scaleFactors, const float* levelSigma2, int* match);
+void pso_line_fuse_best(const PsoKeyLine* kls, int n, const uint8_t* desc, int ndesc, const PsoLineFuseQuery* q, const uint8_t* qdesc, int nq,
+                        int* best_idx, int* best_dist);
+void pso_distinctive_descriptors(const uint8_t* desc, const int32_t* offsets, int npts, int* best);
 int pso_line_match_nnr(const uint8_t* d1, int n1, const uint8_t* d2, int n2, float nnr, int* matches12);
 
 int pso_lsd_detect(const uint8_t* gray, int w, int h, int stride, float* lines, int cap);

@@ -830,3 +830,133 @@ class ORBVocabulary:
             self.close()
         except Exception:
             pass
+
+
+TRIQUERY_DTYPE = np.dtype([("start", "<i4"), ("len", "<i4"), ("x", "<f4"), ("y", "<f4"), ("angle", "<f4"), ("stereo", "<i4")])
+LINEFUSEQUERY_DTYPE = np.dtype([("x1", "<f4"), ("y1", "<f4"), ("x2", "<f4"), ("y2", "<f4"), ("radius", "<f4"), ("level", "<i4")])
+assert TRIQUERY_DTYPE.itemsize == 24 and LINEFUSEQUERY_DTYPE.itemsize == 24
+
+
+class KeyFrameMatcher:
+    """The KeyFrame-rate searches of LocalMapping / LoopClosing (pslfe_kf): ORBmatcher::Fuse (both), SearchBySim3,
+    SearchForTriangulation (src/ORBmatcher.cc:657-1326), LSDmatcher::Fuse / SearchForTriangulation
+    (add_src/LSDmatcher.cpp:705-984) and Map{Point,Line}::ComputeDistinctiveDescriptors, from the point where the host has
+    projected its map points.  Give each host thread its own Context + KeyFrameMatcher."""
+
+    TH_HIGH, TH_LOW = 100, 50
+
+    def __init__(self, ctx=None):
+        self.ctx = ctx or default_context()
+        self._h = C.c_void_p()
+        _check(lib().pslfe_kf_create(self.ctx._h, C.byref(self._h)), "pslfe_kf_create")
+
+    def window_best(self, frame, slot, queries, qdesc, chi2=False, inv_level_sigma2=None):
+        """Candidate loop of Fuse / SearchBySim3 -> (best_idx, best_dist) per projected map point."""
+        q = np.ascontiguousarray(queries, PROJQUERY_DTYPE)
+        qd = np.ascontiguousarray(qdesc, np.uint8).reshape(-1, 32)
+        nq = len(q)
+        bi = np.full(max(nq, 1), -1, np.int32)
+        bd = np.full(max(nq, 1), 0x7fffffff, np.int32)
+        s2 = None if inv_level_sigma2 is None else np.ascontiguousarray(inv_level_sigma2, np.float32)
+        _check(lib().pslfe_kf_window_best(self._h, frame._h, C.c_int(slot), _ptr(q), _ptr(qd), C.c_int(nq), C.c_int(1 if chi2 else 0),
+                                          _ptr(s2), C.c_int(0 if s2 is None else len(s2)), _ptr(bi), _ptr(bd)), "pslfe_kf_window_best")
+        return bi[:nq], bd[:nq]
+
+    def Fuse(self, frame, slot, queries, qdesc, inv_level_sigma2):
+        """ORBmatcher::Fuse(pKF, vpMapPoints, th) src/ORBmatcher.cc:825: -> (bestIdx, fused) with fused = bestDist <= TH_LOW;
+        the caller replaces / adds map points (:950-964)."""
+        bi, bd = self.window_best(frame, slot, queries, qdesc, True, inv_level_sigma2)
+        return bi, bd <= self.TH_LOW
+
+    def FuseSim3(self, frame, slot, queries, qdesc):
+        """ORBmatcher::Fuse(pKF, Scw, vpPoints, th, vpReplacePoint) src/ORBmatcher.cc:968."""
+        bi, bd = self.window_best(frame, slot, queries, qdesc, False)
+        return bi, bd <= self.TH_LOW
+
+    def SearchBySim3(self, frame1, slot1, frame2, slot2, q12, qdesc1, q21, qdesc2):
+        """src/ORBmatcher.cc:1102 -> (nFound, match12)."""
+        q1 = np.ascontiguousarray(q12, PROJQUERY_DTYPE)
+        q2 = np.ascontiguousarray(q21, PROJQUERY_DTYPE)
+        d1 = np.ascontiguousarray(qdesc1, np.uint8).reshape(-1, 32)
+        d2 = np.ascontiguousarray(qdesc2, np.uint8).reshape(-1, 32)
+        m = np.full(max(len(q1), 1), -1, np.int32)
+        nf = C.c_int()
+        _check(lib().pslfe_kf_search_by_sim3(self._h, frame1._h, C.c_int(slot1), frame2._h, C.c_int(slot2), _ptr(q1), _ptr(d1),
+                                             C.c_int(len(q1)), _ptr(q2), _ptr(d2), C.c_int(len(q2)), _ptr(m), C.byref(nf)),
+               "pslfe_kf_search_by_sim3")
+        return nf.value, m[:len(q1)]
+
+    def SearchForTriangulation(self, frame2, slot2, fidx2, taken2, queries, qdesc, F12, epipole, scale_factors, level_sigma2,
+                               bOnlyStereo=False, checkOri=True):
+        """src/ORBmatcher.cc:657 -> (nmatches, match per query); vMatchedPairs = the matched (idx1, idx2) sorted by idx1."""
+        fidx = np.ascontiguousarray(fidx2, np.int32)
+        tk = np.ascontiguousarray(taken2, np.uint8)
+        q = np.ascontiguousarray(queries, TRIQUERY_DTYPE)
+        qd = np.ascontiguousarray(qdesc, np.uint8).reshape(-1, 32)
+        F = np.ascontiguousarray(F12, np.float32).reshape(9)
+        sf = np.ascontiguousarray(scale_factors, np.float32)
+        s2 = np.ascontiguousarray(level_sigma2, np.float32)
+        match = np.full(max(len(q), 1), -1, np.int32)
+        nm = C.c_int()
+        _check(lib().pslfe_kf_search_for_triangulation(self._h, frame2._h, C.c_int(slot2), _ptr(fidx), C.c_int(len(fidx)), _ptr(tk), _ptr(q),
+                                                       _ptr(qd), C.c_int(len(q)), _ptr(F), C.c_float(epipole[0]), C.c_float(epipole[1]),
+                                                       C.c_int(1 if bOnlyStereo else 0), C.c_int(1 if checkOri else 0), _ptr(sf), _ptr(s2),
+                                                       C.c_int(len(sf)), _ptr(match), C.byref(nm)), "pslfe_kf_search_for_triangulation")
+        return nm.value, match[:len(q)]
+
+    def LineFuse(self, keylines, desc, queries, qdesc):
+        """Search of LSDmatcher::Fuse add_src/LSDmatcher.cpp:933-958 -> (bestIdx, bestDist)."""
+        kl = np.ascontiguousarray(keylines, KEYLINE_DTYPE)
+        d = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+        q = np.ascontiguousarray(queries, LINEFUSEQUERY_DTYPE)
+        qd = np.ascontiguousarray(qdesc, np.uint8).reshape(-1, 32)
+        bi = np.full(max(len(q), 1), -1, np.int32)
+        bd = np.full(max(len(q), 1), 256, np.int32)
+        _check(lib().pslfe_kf_line_fuse_best(self._h, _ptr(kl), C.c_int(len(kl)), _ptr(d), C.c_int(len(d)), _ptr(q), _ptr(qd), C.c_int(len(q)),
+                                             _ptr(bi), _ptr(bd)), "pslfe_kf_line_fuse_best")
+        return bi[:len(q)], bd[:len(q)]
+
+    def ComputeDistinctiveDescriptors(self, desc, offsets):
+        """src/MapPoint.cc:242-304 for many map points / lines at once -> best row per point (relative to its run)."""
+        d = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+        off = np.ascontiguousarray(offsets, np.int32)
+        npts = len(off) - 1
+        best = np.full(max(npts, 1), -1, np.int32)
+        _check(lib().pslfe_kf_distinctive_descriptors(self._h, _ptr(d), _ptr(off), C.c_int(npts), _ptr(best)),
+               "pslfe_kf_distinctive_descriptors")
+        return best[:npts]
+
+    def close(self):
+        if self._h:
+            lib().pslfe_kf_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _lsd_search_for_triangulation(self, ldesc1, ldesc2, has_mapline1, has_mapline2, TH=None, isDouble=True):
+    """LSDmatcher::SearchForTriangulation add_src/LSDmatcher.cpp:705-781: FrameBFMatch both ways, mutual check, lines that
+    already have a MapLine dropped.  TH = TH_LOW with the pair-vector overload (:705), TH_HIGH with the vector<int> one (:744).
+    -> (nmatches, vMatchedPairs as an int array: index in KF2 or -1)."""
+    TH = self.TH_LOW if TH is None else TH
+    d1 = np.ascontiguousarray(ldesc1, np.uint8).reshape(-1, 32)
+    d2 = np.ascontiguousarray(ldesc2, np.uint8).reshape(-1, 32)
+    out = np.full(len(d1), -1, np.int32)
+    if len(d1) == 0 or len(d2) == 0:
+        return 0, out
+    m12 = self.FrameBFMatch(d1, d2, TH)
+    m21 = self.FrameBFMatch(d2, d1, TH)
+    n = 0
+    for i, j in enumerate(m12):
+        if j < 0 or (isDouble and m21[j] != i) or has_mapline1[i] or has_mapline2[j]:
+            continue
+        out[i] = j
+        n += 1
+    return n, out
+
+
+LSDmatcher.SearchForTriangulation = _lsd_search_for_triangulation

@@ -364,5 +364,60 @@ private:
     pslfe_vocab* h_ = nullptr;
 };
 
+// == the KeyFrame-rate searches of LocalMapping / LoopClosing (pslfe_kf): ORBmatcher::Fuse (both overloads), SearchBySim3,
+//    SearchForTriangulation (src/ORBmatcher.cc:657-1326), the search of LSDmatcher::Fuse (add_src/LSDmatcher.cpp:933-958) and
+//    Map{Point,Line}::ComputeDistinctiveDescriptors, from the point where the host has projected its map points.  One per host
+//    thread, on that thread's own Context.
+class KeyFrameMatcher {
+public:
+    static constexpr int TH_HIGH = 100, TH_LOW = 50;
+    explicit KeyFrameMatcher(Context& ctx) { check(pslfe_kf_create(ctx.get(), &h_), "pslfe_kf_create"); }
+    ~KeyFrameMatcher() { pslfe_kf_destroy(h_); }
+    KeyFrameMatcher(const KeyFrameMatcher&) = delete;
+    KeyFrameMatcher& operator=(const KeyFrameMatcher&) = delete;
+
+    // candidate loop of Fuse / SearchBySim3; invLevelSigma2 != nullptr selects the reprojection gates of Fuse(pKF, vpMapPoints, th)
+    void WindowBest(FrameGrid& kf, int slot, const std::vector<PslProjQuery>& q, const std::vector<uint8_t>& qdesc,
+                    const std::vector<float>* invLevelSigma2, std::vector<int32_t>& bestIdx, std::vector<int32_t>& bestDist) {
+        bestIdx.assign(q.size(), -1); bestDist.assign(q.size(), 0x7fffffff);
+        check(pslfe_kf_window_best(h_, kf.get(), slot, q.data(), qdesc.data(), (int)q.size(), invLevelSigma2 ? 1 : 0,
+                                   invLevelSigma2 ? invLevelSigma2->data() : nullptr, invLevelSigma2 ? (int)invLevelSigma2->size() : 0,
+                                   bestIdx.data(), bestDist.data()), "pslfe_kf_window_best");
+    }
+    int SearchBySim3(FrameGrid& kf1, int slot1, FrameGrid& kf2, int slot2, const std::vector<PslProjQuery>& q12, const std::vector<uint8_t>& qdesc1,
+                     const std::vector<PslProjQuery>& q21, const std::vector<uint8_t>& qdesc2, std::vector<int32_t>& match12) {
+        match12.assign(q12.size(), -1);
+        int nf = 0;
+        check(pslfe_kf_search_by_sim3(h_, kf1.get(), slot1, kf2.get(), slot2, q12.data(), qdesc1.data(), (int)q12.size(), q21.data(), qdesc2.data(),
+                                      (int)q21.size(), match12.data(), &nf), "pslfe_kf_search_by_sim3");
+        return nf;
+    }
+    int SearchForTriangulation(FrameGrid& kf2, int slot2, const std::vector<int32_t>& fidx2, const std::vector<uint8_t>& taken2,
+                               const std::vector<PslTriQuery>& q, const std::vector<uint8_t>& qdesc, const float F12[9], float ex, float ey,
+                               bool bOnlyStereo, bool checkOrientation, const std::vector<float>& scaleFactors, const std::vector<float>& levelSigma2,
+                               std::vector<int32_t>& match) {
+        match.assign(q.size(), -1);
+        int nm = 0;
+        check(pslfe_kf_search_for_triangulation(h_, kf2.get(), slot2, fidx2.data(), (int)fidx2.size(), taken2.data(), q.data(), qdesc.data(),
+                                                (int)q.size(), F12, ex, ey, bOnlyStereo, checkOrientation, scaleFactors.data(), levelSigma2.data(),
+                                                (int)scaleFactors.size(), match.data(), &nm), "pslfe_kf_search_for_triangulation");
+        return nm;
+    }
+    void LineFuse(const std::vector<PslKeyLine>& kls, const std::vector<uint8_t>& desc, const std::vector<PslLineFuseQuery>& q,
+                  const std::vector<uint8_t>& qdesc, std::vector<int32_t>& bestIdx, std::vector<int32_t>& bestDist) {
+        bestIdx.assign(q.size(), -1); bestDist.assign(q.size(), 256);
+        check(pslfe_kf_line_fuse_best(h_, kls.data(), (int)kls.size(), desc.data(), (int)desc.size() / 32, q.data(), qdesc.data(), (int)q.size(),
+                                      bestIdx.data(), bestDist.data()), "pslfe_kf_line_fuse_best");
+    }
+    // offsets: npts + 1 entries; returns the best row of every point relative to its run
+    std::vector<int32_t> ComputeDistinctiveDescriptors(const std::vector<uint8_t>& desc, const std::vector<int32_t>& offsets) {
+        std::vector<int32_t> best(offsets.empty() ? 0 : offsets.size() - 1, -1);
+        check(pslfe_kf_distinctive_descriptors(h_, desc.data(), offsets.data(), (int)best.size(), best.data()), "pslfe_kf_distinctive_descriptors");
+        return best;
+    }
+private:
+    pslfe_kf* h_ = nullptr;
+};
+
 }  // namespace pslfe
 #endif

@@ -468,3 +468,75 @@ def compute_bow(children, node_desc, node_weight, node_word, L, desc, levelsup=4
     o["fv_node"], o["fv_start"] = o["fv_node"][:nf.value], o["fv_start"][:nf.value + 1]
     o["fv_idx"] = o["fv_idx"][:int(o["fv_start"][nf.value])] if nf.value else o["fv_idx"][:0]
     return o
+
+
+# ---- KeyFrame-rate matchers (oracle/kf_oracle.cpp) ------------------------------------------------------------------
+TRIQUERY_DTYPE = np.dtype([("start", "<i4"), ("len", "<i4"), ("x", "<f4"), ("y", "<f4"), ("angle", "<f4"), ("stereo", "<i4")])
+LINEFUSEQUERY_DTYPE = np.dtype([("x1", "<f4"), ("y1", "<f4"), ("x2", "<f4"), ("y2", "<f4"), ("radius", "<f4"), ("level", "<i4")])
+
+
+def window_best(kps, desc, uright, bounds, queries, qdesc, chi2=False, inv_sigma2=None):
+    L = load()
+    kps = np.ascontiguousarray(kps, KEYPOINT_DTYPE); desc = np.ascontiguousarray(desc, np.uint8)
+    ur = np.full(len(kps), -1, np.float32) if uright is None else np.ascontiguousarray(uright, np.float32)
+    q = np.ascontiguousarray(queries, PROJQUERY_DTYPE); qd = np.ascontiguousarray(qdesc, np.uint8)
+    b = np.array(bounds, np.float32)
+    s2 = np.zeros(16, np.float32) if inv_sigma2 is None else np.ascontiguousarray(inv_sigma2, np.float32)
+    bi = np.full(max(len(q), 1), -1, np.int32); bd = np.zeros(max(len(q), 1), np.int32)
+    L.pso_window_best.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                  C.c_void_p, C.c_void_p, C.c_void_p]
+    L.pso_window_best.restype = None
+    L.pso_window_best(_p(kps), _p(desc), _p(ur), len(kps), _p(b), _p(q), _p(qd), len(q), int(chi2), _p(s2), _p(bi), _p(bd))
+    return bi[:len(q)], bd[:len(q)]
+
+
+def search_by_sim3(kps1, desc1, bounds1, kps2, desc2, bounds2, q12, qdesc1, q21, qdesc2):
+    L = load()
+    kps1 = np.ascontiguousarray(kps1, KEYPOINT_DTYPE); kps2 = np.ascontiguousarray(kps2, KEYPOINT_DTYPE)
+    desc1 = np.ascontiguousarray(desc1, np.uint8); desc2 = np.ascontiguousarray(desc2, np.uint8)
+    q12 = np.ascontiguousarray(q12, PROJQUERY_DTYPE); q21 = np.ascontiguousarray(q21, PROJQUERY_DTYPE)
+    qdesc1 = np.ascontiguousarray(qdesc1, np.uint8); qdesc2 = np.ascontiguousarray(qdesc2, np.uint8)
+    assert len(q12) == len(kps1) and len(q21) == len(kps2)
+    b1 = np.array(bounds1, np.float32); b2 = np.array(bounds2, np.float32)
+    m = np.full(max(len(kps1), 1), -1, np.int32)
+    L.pso_search_by_sim3.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p] + [C.c_void_p] * 5
+    nf = L.pso_search_by_sim3(_p(kps1), _p(desc1), len(kps1), _p(b1), _p(kps2), _p(desc2), len(kps2), _p(b2), _p(q12), _p(qdesc1), _p(q21),
+                              _p(qdesc2), _p(m))
+    return nf, m[:len(kps1)]
+
+
+def search_for_triangulation(kps2, desc2, uright2, taken2, fidx2, queries, qdesc, F12, epipole, scale_factors, level_sigma2, only_stereo,
+                             check_ori):
+    L = load()
+    kps2 = np.ascontiguousarray(kps2, KEYPOINT_DTYPE); desc2 = np.ascontiguousarray(desc2, np.uint8)
+    ur = np.ascontiguousarray(uright2, np.float32); tk = np.ascontiguousarray(taken2, np.uint8)
+    fidx = np.ascontiguousarray(fidx2, np.int32); q = np.ascontiguousarray(queries, TRIQUERY_DTYPE); qd = np.ascontiguousarray(qdesc, np.uint8)
+    F = np.ascontiguousarray(F12, np.float32).reshape(9)
+    sf = np.ascontiguousarray(scale_factors, np.float32); s2 = np.ascontiguousarray(level_sigma2, np.float32)
+    match = np.full(max(len(q), 1), -1, np.int32)
+    L.pso_search_for_triangulation.argtypes = [C.c_void_p] * 7 + [C.c_int, C.c_void_p, C.c_float, C.c_float, C.c_int, C.c_int, C.c_void_p,
+                                                                   C.c_void_p, C.c_void_p]
+    nm = L.pso_search_for_triangulation(_p(kps2), _p(desc2), _p(ur), _p(tk), _p(fidx), _p(q), _p(qd), len(q), _p(F), float(epipole[0]),
+                                        float(epipole[1]), int(only_stereo), int(check_ori), _p(sf), _p(s2), _p(match))
+    return nm, match[:len(q)]
+
+
+def line_fuse_best(kls, desc, queries, qdesc):
+    L = load()
+    kls = np.ascontiguousarray(kls, KEYLINE_DTYPE); desc = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+    q = np.ascontiguousarray(queries, LINEFUSEQUERY_DTYPE); qd = np.ascontiguousarray(qdesc, np.uint8)
+    bi = np.full(max(len(q), 1), -1, np.int32); bd = np.zeros(max(len(q), 1), np.int32)
+    L.pso_line_fuse_best.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    L.pso_line_fuse_best.restype = None
+    L.pso_line_fuse_best(_p(kls), len(kls), _p(desc), len(desc), _p(q), _p(qd), len(q), _p(bi), _p(bd))
+    return bi[:len(q)], bd[:len(q)]
+
+
+def distinctive_descriptors(desc, offsets):
+    L = load()
+    desc = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32); off = np.ascontiguousarray(offsets, np.int32)
+    best = np.full(max(len(off) - 1, 1), -1, np.int32)
+    L.pso_distinctive_descriptors.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    L.pso_distinctive_descriptors.restype = None
+    L.pso_distinctive_descriptors(_p(desc), _p(off), len(off) - 1, _p(best))
+    return best[:len(off) - 1]
