@@ -485,7 +485,8 @@ struct LsdW {
     const float* ang;
     const double* mod;
     const float4* trig;
-    uint32_t* used;   // bitmap: LDS (k_lsd_grow2) or HBM (k_lsd_grow3, gused = true)
+    uint32_t* used;   // bitmap in LDS (k_lsd_grow2)
+    uint8_t* usedb;   // one byte per pixel in HBM (k_lsd_grow3, gused = true): plain byte stores instead of read-modify-write
     bool gused;
     uint32_t* ring;   // LDS mirror of reg[idx & (RING-1)]
     double* term;     // LDS [3][64]
@@ -586,69 +587,94 @@ __device__ int lsdw_region_grow(const LsdW& F, int sx, int sy, double* reg_angle
     return reg_size;
 }
 
-// ---- variant with the `used` bitmap in HBM (L2-resident: 24 KB per frame) --------------------------
-// Frees the 24 KB of LDS per wave, so 4-5 waves per SIMD can overlap their serial chains.  The bitmap is
-// written with agent-scope atomics (lane 0) and read with agent-scope relaxed loads (L1 bypass); inside a
-// round every lane keeps its own "used" flag, updated by comparing its pixel with each pixel that is added.
-__device__ __forceinline__ uint32_t lsdg_word(const LsdW& F, int w) {
-    return __hip_atomic_load(&F.used[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+// ---- variant with the `used` map in HBM (L2-resident) ---------------------------------------------------
+// Frees the 24 KB of LDS per wave, so 6 waves per SIMD can overlap their serial chains.  One byte per pixel, written by
+// lane 0 with agent-scope stores and read with agent-scope relaxed loads (L1 bypass); inside a round every lane keeps its own
+// "used" flag, updated by comparing its pixel with each pixel that is added.
+__device__ __forceinline__ bool lsdg_used(const LsdW& F, int a) {
+    return __hip_atomic_load(&F.usedb[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
 }
-__device__ __forceinline__ bool lsdg_used(const LsdW& F, int a) { return (lsdg_word(F, a >> 5) >> (a & 31)) & 1u; }
-__device__ __forceinline__ void lsdg_set(const LsdW& F, int a) {
-    if (F.lane == 0) __hip_atomic_fetch_or(&F.used[a >> 5], 1u << (a & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+__device__ __forceinline__ void lsdg_mark(const LsdW& F, int a, uint8_t v) {
+    __hip_atomic_store(&F.usedb[a], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// Queue push of k_lsd_grow3: the LDS ring is the queue; a block of 512 entries goes to HBM (coalesced, all lanes) when it is
+// complete, long before the ring wraps over it, so that lsdw_reg finds older entries there.  Called by all lanes.
+__device__ __forceinline__ void lsdg_push(const LsdW& F, int idx, uint32_t v, int cell) {
+    if (F.lane == 0) {
+        lsdg_mark(F, cell, 1);
+        F.ring[idx & (PSL_LSD_RING - 1)] = v;
+    }
+    if (((idx + 1) & 511) == 0) {
+        __builtin_amdgcn_wave_barrier();
+        const int b0 = idx + 1 - 512;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) F.reg[b0 + t * 64 + F.lane] = F.ring[(b0 + t * 64 + F.lane) & (PSL_LSD_RING - 1)];
+    }
+}
+
+// |theta - ad| folded into [0, pi] and compared with prec, as lsdw_aligned but without branches: both differences are formed
+// and one is selected (the serial acceptance chain below executes this once per accepted pixel).
+__device__ __forceinline__ bool lsdg_aligned(double ad, double theta, double prec) {
+    const double d = __builtin_fabs(PSL_DSUB(theta, ad));
+    const double d2 = __builtin_fabs(PSL_DSUB(d, 2 * PSL_PI));
+    return (d > (3 * PSL_PI) / 2 ? d2 : d) <= prec;
 }
 
 __device__ int lsdg_region_grow(const LsdW& F, int sx, int sy, double* reg_angle_out, double prec) {
     int reg_size = 1;
     const int addr0 = sx + sy * F.W;
-    lsdw_push(F, 0, (uint32_t)sx | ((uint32_t)sy << 16));
+    lsdg_push(F, 0, (uint32_t)sx | ((uint32_t)sy << 16), addr0);
     double reg_angle = PSL_DMUL((double)F.ang[addr0], PSL_DEG2RAD);
     const float4 t0 = F.trig[addr0];
     float sumdx = t0.z, sumdy = t0.w;
-    lsdg_set(F, addr0);
     const int e = F.lane / 9, k = F.lane - e * 9, ky = k / 3, kx = k - ky * 3;
     int i = 0;
     while (i < reg_size) {
         const int nb = min(7, reg_size - i);
-        // every bitmap update issued so far must have landed before this round reads (no prefetch of the next round:
-        // the kernel is bound by instruction issue, not latency - measured 4 % faster without it)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        float a = PSL_LSD_NOTDEF, sn = 0.f, cs = 0.f;
-        uint32_t xy = 0;
-        int cidx = 0;
-        bool u = true;
-        if (F.lane < 63 && e < nb) {
-            const uint32_t rp = lsdw_reg(F, i + e, reg_size);
-            const int nx = (int)(rp & 0xffff) + kx - 1, ny = (int)(rp >> 16) + ky - 1;
-            if (nx >= 0 && nx < F.W && ny >= 0 && ny < F.H) {
-                cidx = nx + ny * F.W;
-                a = F.ang[cidx];
-                const float2 t = *reinterpret_cast<const float2*>(&F.trig[cidx]);
-                cs = t.x; sn = t.y;
-                xy = (uint32_t)nx | ((uint32_t)ny << 16);
-                u = lsdg_used(F, cidx);
-            }
+        // A round costs two memory round trips in series if it is written naively: wait for the marks of the previous round,
+        // then fetch the neighbours.  The angle and its cosine / sine do not depend on the marks, so they are requested FIRST
+        // (unconditionally: clamped address, so that exactly two vector-memory instructions follow the marks), then
+        // `s_waitcnt vmcnt(2)` - vector-memory operations complete in issue order on gfx9 - waits for everything older than these
+        // two loads, i.e. for every mark issued so far, and only the `used` bytes are read after it.
+        const bool mine = F.lane < 63 && e < nb;
+        const int qe = i + (mine ? e : 0);
+        // the queue entry comes from the LDS ring through an explicit LDS pointer: a select between the (generic) ring pointer
+        // and the HBM queue is compiled into ONE flat load, and the wait for a flat load also waits for the marks
+        typedef __attribute__((address_space(3))) const uint32_t lds_u32;
+        uint32_t rp = ((lds_u32*)F.ring)[qe & (PSL_LSD_RING - 1)];
+        if (reg_size - i > PSL_LSD_RING) {  // uniform, rare: blob regions whose frontier lags > 1024 entries
+            const uint32_t g = F.reg[qe];
+            asm volatile("v_mov_b32 %0, %1" : "=v"(rp) : "v"(g));  // consumed here, so that its wait is not placed after the join
         }
-        const bool cand0 = a != PSL_LSD_NOTDEF;
+        const int nx = (int)(rp & 0xffff) + kx - 1, ny = (int)(rp >> 16) + ky - 1;
+        const bool inside = mine && nx >= 0 && nx < F.W && ny >= 0 && ny < F.H;
+        const int cidx = inside ? nx + ny * F.W : addr0;
+        float a = F.ang[cidx];
+        const float2 t = *reinterpret_cast<const float2*>(&F.trig[cidx]);
+        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        const bool u = lsdg_used(F, cidx) || !inside;
+        const float cs = t.x, sn = t.y;
+        const uint32_t xy = inside ? ((uint32_t)nx | ((uint32_t)ny << 16)) : 0xffffffffu;
+        if (!inside) a = PSL_LSD_NOTDEF;
         const double ad = PSL_DMUL((double)a, PSL_DEG2RAD);
-        int cursor = 0;
-        while (true) {
-            const bool ok = cand0 && F.lane >= cursor && !u && lsdw_aligned(ad, reg_angle, prec);
-            const unsigned long long m = __ballot(ok);
+        // lanes are ordered (entry, neighbour) exactly as the reference visits them.  `live` = lanes that can still join in this
+        // round: a defined angle, not used, behind the last accepted lane, not a second copy of an accepted pixel.  Take the
+        // first live lane aligned with the CURRENT angle, add it, re-test the rest.
+        unsigned long long live = __ballot(a != PSL_LSD_NOTDEF && !u);
+        while (live) {
+            const unsigned long long m = __ballot(lsdg_aligned(ad, reg_angle, prec)) & live;
             if (!m) break;
-            const int L = __ffsll((long long)m) - 1;
+            const int L = __ffsll((long long)m) - 1;  // wave-uniform: v_readlane instead of ds_bpermute
             const uint32_t xyL = (uint32_t)__builtin_amdgcn_readlane((int)xy, L);
             const int cL = __builtin_amdgcn_readlane(cidx, L);
             const float csL = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cs), L));
             const float snL = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sn), L));
-            if (cand0 && xy == xyL) u = true;  // duplicates of this pixel in the current round
-            lsdg_set(F, cL);
-            lsdw_push(F, reg_size, xyL);
+            live &= ~((2ull << L) - 1ull) & ~__ballot(xy == xyL);
+            lsdg_push(F, reg_size, xyL, cL);
             ++reg_size;
             sumdx = PSL_FADD(sumdx, csL);
             sumdy = PSL_FADD(sumdy, snL);
             reg_angle = PSL_DMUL((double)psl_fast_atan2(sumdy, sumdx), PSL_DEG2RAD);
-            cursor = L + 1;
         }
         i += nb;
     }
@@ -738,7 +764,7 @@ __device__ int lsdw_refine(const LsdW& F, int reg_size, double reg_angle, double
         if (j < reg_size) {
             const uint32_t rp = lsdw_reg(F, j, reg_size);
             const int px = (int)(rp & 0xffff), py = (int)(rp >> 16), a = px + py * F.W;
-            atomicAnd(&F.used[a >> 5], ~(1u << (a & 31)));
+            if (F.gused) lsdg_mark(F, a, 0); else atomicAnd(&F.used[a >> 5], ~(1u << (a & 31)));
             if (__dsqrt_rn(psl_dist_sq(xc, yc, (double)px, (double)py)) < rec->width) {
                 in = true;
                 ang_d = psl_angle_diff_signed(PSL_DMUL((double)F.ang[a], PSL_DEG2RAD), ang_c);
@@ -772,7 +798,10 @@ __device__ int lsdw_refine(const LsdW& F, int reg_size, double reg_angle, double
             if (psl_dist_sq(xc, yc, (double)px, (double)py) > radSq) {
                 const int a = px + py * F.W;
                 const uint32_t last = F.reg[reg_size - 1];
-                if (F.lane == 0) { atomicAnd(&F.used[a >> 5], ~(1u << (a & 31))); F.reg[i] = last; F.reg[reg_size - 1] = rp; }
+                if (F.lane == 0) {
+                    if (F.gused) lsdg_mark(F, a, 0); else atomicAnd(&F.used[a >> 5], ~(1u << (a & 31)));
+                    F.reg[i] = last; F.reg[reg_size - 1] = rp;
+                }
                 __builtin_amdgcn_wave_barrier();
                 --reg_size;
                 --i;
@@ -855,7 +884,7 @@ __global__ __launch_bounds__(64) void k_lsd_grow2(LineParams P, const float* __r
                            // 9 % faster per frame than 5 with 4096-5120; 7 (72 VGPRs, 18 spills) gains nothing more
 #endif
 __global__ __launch_bounds__(64, PSL_GROW_WAVES) void k_lsd_grow3(LineParams P, const float* __restrict__ angdeg, const double* __restrict__ modgrad,
-                                                   const float4* __restrict__ trig, uint32_t* __restrict__ usedbits, uint32_t* __restrict__ reg,
+                                                   const float4* __restrict__ trig, uint8_t* __restrict__ usedmap, uint32_t* __restrict__ reg,
                                                    float* __restrict__ seg, int* __restrict__ nseg) {
     __shared__ uint32_t s_ring[PSL_LSD_RING];
     __shared__ double s_term[3 * 64];
@@ -865,40 +894,61 @@ __global__ __launch_bounds__(64, PSL_GROW_WAVES) void k_lsd_grow3(LineParams P, 
     LsdW F;
     F.W = P.W; F.H = P.H; F.lane = lane;
     F.ang = angdeg + frame * npx; F.mod = modgrad + frame * npx; F.trig = trig + frame * npx; F.reg = reg + frame * npx;
-    F.used = usedbits + (size_t)frame * words; F.gused = true; F.ring = s_ring; F.term = s_term;
-    for (int i = lane; i < words; i += 64) __hip_atomic_store(&F.used[i], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    F.used = nullptr; F.usedb = usedmap + (size_t)frame * npx; F.gused = true; F.ring = s_ring; F.term = s_term;
+    {   // npx is a multiple of 4 or the tail is cleared bytewise; the frame's map starts 4-aligned when npx % 4 == 0
+        const size_t head = (4 - ((size_t)F.usedb & 3)) & 3;
+        uint32_t* w = reinterpret_cast<uint32_t*>(F.usedb + head);
+        const size_t nw = (npx - head) >> 2;
+        for (size_t i = lane; i < nw; i += 64) __hip_atomic_store(&w[i], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((size_t)lane < head) lsdg_mark(F, lane, 0);
+        for (size_t i = head + (nw << 2) + lane; i < npx; i += 64) lsdg_mark(F, (int)i, 0);
+    }
+    (void)words;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     float* out = seg + (size_t)frame * P.maxseg * 4;
     int count = 0;
     const int scan_end = (P.H - 1) * P.W;
     for (int base = 0; base < scan_end; base += 256) {
-        float a4[4];
-        uint32_t u4[4];
+        // four 64-pixel rows per trip, their loads in flight together; what is kept of them is wave-uniform: the masks of
+        // pixels with a defined angle and of used pixels.  The seed loop below exists ONCE (not per row): the kernel's code is
+        // dominated by the inlined region growing, and four copies of it did not fit the instruction cache.
+        unsigned long long dm[4], um[4];
+        {
+            float a4[4];
+            uint32_t u4[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int ad = base + q * 64 + lane;
-            a4[q] = ad < scan_end ? F.ang[ad] : PSL_LSD_NOTDEF;
-            u4[q] = ad < scan_end ? lsdg_word(F, ad >> 5) : 0xffffffffu;
+            for (int q = 0; q < 4; ++q) {
+                const int ad = base + q * 64 + lane;
+                a4[q] = ad < scan_end ? F.ang[ad] : PSL_LSD_NOTDEF;
+                u4[q] = ad < scan_end ? (uint32_t)lsdg_used(F, ad) : 1u;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                dm[q] = __ballot(a4[q] != PSL_LSD_NOTDEF);  // column W-1 and row H-1 are NOTDEF by construction
+                um[q] = __ballot(u4[q] != 0);
+            }
         }
         // The bitmap changes only through the regions grown here: after each processed seed the remaining candidates
         // of the 64-pixel row are reconciled with ONE bitmap read per lane (not one read + round trip per candidate),
         // and the rows further down the chunk are re-read when their turn comes.  A pixel a region took and its
         // refinement released again is still a candidate, as in the reference's raster scan.
         bool stale = false;
-#pragma unroll
+#pragma nounroll
         for (int q = 0; q < 4; ++q) {
+            const unsigned long long dmq = q == 0 ? dm[0] : q == 1 ? dm[1] : q == 2 ? dm[2] : dm[3];
+            unsigned long long umq = q == 0 ? um[0] : q == 1 ? um[1] : q == 2 ? um[2] : um[3];
+            if (!dmq) continue;
             const int ad = base + q * 64 + lane;
             if (stale) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                u4[q] = ad < scan_end ? lsdg_word(F, ad >> 5) : 0xffffffffu;
+                umq = __ballot(ad < scan_end ? lsdg_used(F, ad) : true);
             }
-            unsigned long long mask = __ballot(a4[q] != PSL_LSD_NOTDEF && !((u4[q] >> (ad & 31)) & 1u));
+            unsigned long long mask = dmq & ~umq;
             bool dirty = false;
             while (mask) {
                 if (dirty) {
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    const uint32_t w = ad < scan_end ? lsdg_word(F, ad >> 5) : 0xffffffffu;
-                    mask &= __ballot(!((w >> (ad & 31)) & 1u));
+                    mask &= __ballot(ad < scan_end && !lsdg_used(F, ad));
                     dirty = false;
                     if (!mask) break;
                 }

@@ -114,7 +114,6 @@ struct pslfe_line {
         PSL_HIP(hipMalloc((void**)&d_modgrad, npx * F * sizeof(double)));
         PSL_HIP(hipMalloc((void**)&d_trig, npx * F * sizeof(float4)));
         PSL_HIP(hipMalloc((void**)&d_used, npx * F));
-        PSL_HIP(hipMalloc((void**)&d_usedbits, ((npx + 31) / 32) * sizeof(uint32_t) * F));
         PSL_HIP(hipMalloc((void**)&d_reg, npx * F * sizeof(uint32_t)));
         PSL_HIP(hipMalloc((void**)&d_seg, (size_t)Q.maxseg * 4 * sizeof(float) * F));
         PSL_HIP(hipMalloc((void**)&d_nseg, F * sizeof(int)));
@@ -179,7 +178,7 @@ struct pslfe_line {
             const size_t lds = (((size_t)P.W * P.H + 31) / 32) * sizeof(uint32_t);
             const char* variant = getenv("PSLFE_LSD_GROW");  // "serial" | "lds" | default: HBM bitmap, many waves per SIMD
             if (!variant || (strcmp(variant, "serial") != 0 && strcmp(variant, "lds") != 0)) {
-                k_lsd_grow3<<<F, 64, 0, st>>>(P, d_angdeg, d_modgrad, d_trig, d_usedbits, d_reg, d_seg, d_nseg);
+                k_lsd_grow3<<<F, 64, 0, st>>>(P, d_angdeg, d_modgrad, d_trig, d_used, d_reg, d_seg, d_nseg);
             } else if (lds <= 140 * 1024 && strcmp(variant, "lds") == 0) {
                 if (lds > 48 * 1024) PSL_HIP(hipFuncSetAttribute((const void*)k_lsd_grow2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 k_lsd_grow2<<<F, 64, lds, st>>>(P, d_angdeg, d_modgrad, d_trig, d_reg, d_seg, d_nseg);
