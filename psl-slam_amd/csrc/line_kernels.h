@@ -694,36 +694,67 @@ __device__ __forceinline__ double lsdw_wave_min(double v) {
     return v;
 }
 
+// "Terms in parallel, sums in series", three sums at a time: the 64 terms of each of three sums are staged in LDS rows
+// (F.term[r * 64 + t]); lane r (r = 0, 1, 2) then adds ITS row strictly in index order, so one dependent f64 add per element
+// serves all three sums (every lane executes the adds anyway; lanes >= 3 repeat lane 0).  Rows are padded with +0.0 to the
+// block: x + (+0.0) == x for every x a running sum that starts at +0.0 can hold (it is never -0.0), and a difference is
+// staged negated (x - t == x + (-t) in IEEE arithmetic), so the padded sums are bit-identical to the reference's loops.
+typedef __attribute__((address_space(3))) double lds_f64;
+__device__ __forceinline__ double lsdw_sum_rows(const LsdW& F, double acc, int cnt) {
+    const lds_f64* my = (const lds_f64*)F.term + (F.lane < 3 ? F.lane : 0) * 64;
+    for (int t = 0; t < cnt; t += 8) {
+        double v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = my[t + k];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc = PSL_DADD(acc, v[k]);
+    }
+    return acc;
+}
+__device__ __forceinline__ double lsdw_lane_f64(double v, int lane) {
+    const long long b = __double_as_longlong(v);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)b, lane);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(b >> 32), lane);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
 __device__ void lsdw_region2rect(const LsdW& F, int reg_size, double reg_angle, double prec, LsdRect* rec) {
-    double x = 0, y = 0, sum = 0;
+    double acc = 0;  // lane 0: sum x w, lane 1: sum y w, lane 2: sum w
     for (int base = 0; base < reg_size; base += 64) {
         const int j = base + F.lane, cnt = min(64, reg_size - base);
+        double t0 = 0, t1 = 0, t2 = 0;
         if (j < reg_size) {
             const uint32_t rp = lsdw_reg(F, j, reg_size);
             const int px = (int)(rp & 0xffff), py = (int)(rp >> 16);
             const double w = F.mod[px + py * F.W];
-            F.term[F.lane] = PSL_DMUL((double)px, w); F.term[64 + F.lane] = PSL_DMUL((double)py, w); F.term[128 + F.lane] = w;
+            t0 = PSL_DMUL((double)px, w); t1 = PSL_DMUL((double)py, w); t2 = w;
         }
+        F.term[F.lane] = t0; F.term[64 + F.lane] = t1; F.term[128 + F.lane] = t2;
         __builtin_amdgcn_wave_barrier();
-        for (int t = 0; t < cnt; ++t) { x = PSL_DADD(x, F.term[t]); y = PSL_DADD(y, F.term[64 + t]); sum = PSL_DADD(sum, F.term[128 + t]); }
+        acc = lsdw_sum_rows(F, acc, cnt);
         __builtin_amdgcn_wave_barrier();
     }
+    double x = lsdw_lane_f64(acc, 0), y = lsdw_lane_f64(acc, 1);
+    const double sum = lsdw_lane_f64(acc, 2);
     x = x / sum; y = y / sum;
-    double Ixx = 0, Iyy = 0, Ixy = 0;
+    acc = 0;  // lane 0: Ixx, lane 1: Iyy, lane 2: Ixy
     for (int base = 0; base < reg_size; base += 64) {
         const int j = base + F.lane, cnt = min(64, reg_size - base);
+        double t0 = 0, t1 = 0, t2 = 0;
         if (j < reg_size) {
             const uint32_t rp = lsdw_reg(F, j, reg_size);
             const int px = (int)(rp & 0xffff), py = (int)(rp >> 16);
             const double w = F.mod[px + py * F.W];
             const double dx = PSL_DSUB((double)px, x), dy = PSL_DSUB((double)py, y);
-            F.term[F.lane] = PSL_DMUL(PSL_DMUL(dy, dy), w); F.term[64 + F.lane] = PSL_DMUL(PSL_DMUL(dx, dx), w);
-            F.term[128 + F.lane] = PSL_DMUL(PSL_DMUL(dx, dy), w);
+            t0 = PSL_DMUL(PSL_DMUL(dy, dy), w); t1 = PSL_DMUL(PSL_DMUL(dx, dx), w);
+            t2 = -PSL_DMUL(PSL_DMUL(dx, dy), w);  // Ixy -= dx dy w
         }
+        F.term[F.lane] = t0; F.term[64 + F.lane] = t1; F.term[128 + F.lane] = t2;
         __builtin_amdgcn_wave_barrier();
-        for (int t = 0; t < cnt; ++t) { Ixx = PSL_DADD(Ixx, F.term[t]); Iyy = PSL_DADD(Iyy, F.term[64 + t]); Ixy = PSL_DSUB(Ixy, F.term[128 + t]); }
+        acc = lsdw_sum_rows(F, acc, cnt);
         __builtin_amdgcn_wave_barrier();
     }
+    const double Ixx = lsdw_lane_f64(acc, 0), Iyy = lsdw_lane_f64(acc, 1), Ixy = lsdw_lane_f64(acc, 2);
     const double dI = PSL_DSUB(Ixx, Iyy);
     const double lambda = PSL_DMUL(0.5, PSL_DSUB(PSL_DADD(Ixx, Iyy), __dsqrt_rn(PSL_DADD(PSL_DMUL(dI, dI), PSL_DMUL(PSL_DMUL(4.0, Ixy), Ixy)))));
     double theta = (fabs(Ixx) > fabs(Iyy)) ? (double)psl_fast_atan2((float)PSL_DSUB(lambda, Ixx), (float)Ixy)
@@ -755,7 +786,7 @@ __device__ int lsdw_refine(const LsdW& F, int reg_size, double reg_angle, double
     const int x0 = (int)(r0 & 0xffff), y0 = (int)(r0 >> 16);
     const double xc = (double)x0, yc = (double)y0;
     const double ang_c = PSL_DMUL((double)F.ang[x0 + y0 * F.W], PSL_DEG2RAD);
-    double sum = 0, s_sum = 0;
+    double acc = 0;  // lane 0: sum of the angle differences, lane 1: sum of their squares (pixels outside the radius stage +0.0)
     int n = 0;
     for (int base = 0; base < reg_size; base += 64) {
         const int j = base + F.lane, cnt = min(64, reg_size - base);
@@ -770,13 +801,14 @@ __device__ int lsdw_refine(const LsdW& F, int reg_size, double reg_angle, double
                 ang_d = psl_angle_diff_signed(PSL_DMUL((double)F.ang[a], PSL_DEG2RAD), ang_c);
             }
         }
-        F.term[F.lane] = ang_d;
-        const unsigned long long m = __ballot(in);
+        F.term[F.lane] = in ? ang_d : 0.0;
+        F.term[64 + F.lane] = in ? PSL_DMUL(ang_d, ang_d) : 0.0;
+        n += __popcll(__ballot(in));
         __builtin_amdgcn_wave_barrier();
-        for (int t = 0; t < cnt; ++t)
-            if ((m >> t) & 1ull) { const double d = F.term[t]; sum = PSL_DADD(sum, d); s_sum = PSL_DADD(s_sum, PSL_DMUL(d, d)); ++n; }
+        acc = lsdw_sum_rows(F, acc, cnt);
         __builtin_amdgcn_wave_barrier();
     }
+    const double sum = lsdw_lane_f64(acc, 0), s_sum = lsdw_lane_f64(acc, 1);
     const double mean_angle = sum / (double)n;
     const double tau = PSL_DMUL(2.0, __dsqrt_rn(PSL_DADD(PSL_DSUB(s_sum, PSL_DMUL(PSL_DMUL(2.0, mean_angle), sum)) / (double)n, PSL_DMUL(mean_angle, mean_angle))));
     reg_size = F.gused ? lsdg_region_grow(F, x0, y0, &reg_angle, tau) : lsdw_region_grow(F, x0, y0, &reg_angle, tau);
