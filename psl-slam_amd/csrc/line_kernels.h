@@ -18,6 +18,8 @@
 #include "psl_device_math.h"
 
 #define PSL_LSD_NOTDEF (-1024.0f)   // angle map label for "gradient undefined" (stored as f32 degrees)
+#define PSL_SC64_QUAL __host__ __device__ static inline
+#include "psl_sincos64.h"
 #define PSL_PI 3.1415926535897932384626433832795
 #define PSL_DEG2RAD (PSL_PI / 180)
 
@@ -234,20 +236,24 @@ __global__ __launch_bounds__(256) void k_lsd_grad(LineParams P, const double* __
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= P.W || y >= P.H) return;
     const size_t o = (size_t)frame * P.W * P.H + (size_t)y * P.W + x;
-    if (x == P.W - 1 || y == P.H - 1) { angdeg[o] = PSL_LSD_NOTDEF; modgrad[o] = 0.0; trig[o] = make_float4(0, 0, 0, 0); return; }
+    // trig[] is written (and meaningful) only where the angle is defined: k_lsd_grow3 reads it for every neighbour but uses it
+    // only for pixels with a defined angle; not writing 16 B for the other ~85 % of the pixels halves this kernel's HBM writes
+    if (x == P.W - 1 || y == P.H - 1) { angdeg[o] = PSL_LSD_NOTDEF; modgrad[o] = 0.0; return; }
     const double* r0 = scaled + (size_t)frame * P.W * P.H + (size_t)y * P.W;
     const double* r1 = r0 + P.W;
     const double DA = PSL_DSUB(r1[x + 1], r0[x]), BC = PSL_DSUB(r0[x + 1], r1[x]);
     const double gx = PSL_DADD(DA, BC), gy = PSL_DSUB(DA, BC);
     const double norm = __dsqrt_rn(PSL_DADD(PSL_DMUL(gx, gx), PSL_DMUL(gy, gy)) / 4);
     modgrad[o] = norm;
-    if (norm <= P.rho) { angdeg[o] = PSL_LSD_NOTDEF; trig[o] = make_float4(0, 0, 0, 0); return; }
+    if (norm <= P.rho) { angdeg[o] = PSL_LSD_NOTDEF; return; }
     const float deg = psl_fast_atan2((float)gx, (float)(-gy));
     angdeg[o] = deg;
     const double ad = PSL_DMUL((double)deg, PSL_DEG2RAD);
     float sn, cs;
     psl_sincosf((float)ad, &sn, &cs);
-    trig[o] = make_float4(cs, sn, (float)cos(ad), (float)sin(ad));
+    float cd, sd;  // (float)cos(ad), (float)sin(ad): restricted-range evaluation, pinned exhaustively (psl_sincos64.h)
+    psl_cos_sin_2pi_f32(ad, &cd, &sd);
+    trig[o] = make_float4(cs, sn, cd, sd);
 }
 
 // ---------------------------------------------------------------------------------------------
