@@ -149,32 +149,45 @@ __global__ __launch_bounds__(256) void k_lsd_scale_tiled(LineParams P, const uin
     by1 = min(max(s + 1, 0), P.h - 1);
     const int nbc = bx1 - bx0 + 1, nbr = by1 - by0 + 1;  // <= 82, <= 22 for scale 0.8
     const int nic = nbc + 6, nir = nbr + 6;
-    for (int k = tid; k < nir * nic; k += 256) {
-        const int r = k / nic, c = k - r * nic;
-        s_in[r * PSL_LS_IC + c] = img[(size_t)psl_reflect101i(by0 - 3 + r, P.h) * stride + psl_reflect101i(bx0 - 3 + c, P.w)];
+    if (bx0 - 3 >= 0 && bx0 - 3 + nic <= P.w && bx0 - 3 + PSL_LS_IC <= stride) {
+        // no column reflection in this tile (6 of 8 tile columns): whole rows as 22 dwords (unaligned in HBM, aligned in LDS)
+        for (int k = tid; k < nir * (PSL_LS_IC / 4); k += 256) {
+            const int r = k / (PSL_LS_IC / 4), d = k - r * (PSL_LS_IC / 4);
+            uint32_t w;
+            __builtin_memcpy(&w, img + (size_t)psl_reflect101i(by0 - 3 + r, P.h) * stride + (bx0 - 3) + 4 * d, 4);
+            *reinterpret_cast<uint32_t*>(&s_in[r * PSL_LS_IC + 4 * d]) = w;
+        }
+    } else {
+        const uint32_t mic = (1048576u + (uint32_t)nic - 1u) / (uint32_t)nic;  // k / nic == (k * mic) >> 20 for k < 4096
+        for (int k = tid; k < nir * nic; k += 256) {
+            const int r = (int)(((uint32_t)k * mic) >> 20), c = k - r * nic;
+            s_in[r * PSL_LS_IC + c] = img[(size_t)psl_reflect101i(by0 - 3 + r, P.h) * stride + psl_reflect101i(bx0 - 3 + c, P.w)];
+        }
     }
     __syncthreads();
-    // RowFilter: s = k0*S0; s += k1*S1; ...  A thread makes 8 adjacent row sums from 14 input bytes (four aligned
-    // dwords) instead of reading 7 bytes per sum: the kernel was LDS-bound.
+    // RowFilter: s = k0*S0; s += k1*S1; ...  A thread makes 4 adjacent row sums from 10 input bytes (three aligned dwords)
+    // instead of reading 7 bytes per sum (the kernel was LDS-bound); 4 rather than 8 per thread so that the <= 588 work items
+    // fill the 256 threads in 3 even trips (8 per thread: 2 trips, the second one 20 % occupied).
     {
-        const int ngr = (nbc + 7) >> 3;  // <= 11
+        const int ngr = (nbc + 3) >> 2;  // <= 21
+        const uint32_t mgr = (1048576u + (uint32_t)ngr - 1u) / (uint32_t)ngr;
         for (int k = tid; k < nir * ngr; k += 256) {
-            const int r = k / ngr, g = k - r * ngr;
-            const uint32_t* in32 = reinterpret_cast<const uint32_t*>(&s_in[r * PSL_LS_IC + 8 * g]);
-            const uint32_t w0 = in32[0], w1 = in32[1], w2 = in32[2], w3 = in32[3];
-            double v[14];
+            const int r = (int)(((uint32_t)k * mgr) >> 20), g = k - r * ngr;
+            const uint32_t* in32 = reinterpret_cast<const uint32_t*>(&s_in[r * PSL_LS_IC + 4 * g]);
+            const uint32_t w0 = in32[0], w1 = in32[1], w2 = in32[2];
+            double v[10];
 #pragma unroll
-            for (int j = 0; j < 14; ++j) {
-                const uint32_t w = j < 4 ? w0 : (j < 8 ? w1 : (j < 12 ? w2 : w3));
+            for (int j = 0; j < 10; ++j) {
+                const uint32_t w = j < 4 ? w0 : (j < 8 ? w1 : w2);
                 v[j] = (double)((w >> (8 * (j & 3))) & 0xffu);
             }
 #pragma unroll
-            for (int o = 0; o < 8; ++o) {
-                if (8 * g + o < nbc) {
+            for (int o = 0; o < 4; ++o) {
+                if (4 * g + o < nbc) {
                     double acc = PSL_DMUL(P.gk[0], v[o]);
 #pragma unroll
                     for (int j = 1; j < 7; ++j) acc = PSL_DADD(acc, PSL_DMUL(P.gk[j], v[o + j]));
-                    s_rs[r * PSL_LS_BC + 8 * g + o] = acc;
+                    s_rs[r * PSL_LS_BC + 4 * g + o] = acc;
                 }
             }
         }
@@ -202,14 +215,17 @@ __global__ __launch_bounds__(256) void k_lsd_scale_tiled(LineParams P, const uin
         }
     }
     __syncthreads();
+    int sx;
+    float fx;
+    psl_lsd_src(min(dx0 + (tid & 63), P.W - 1), P.w, &sx, &fx, true);  // a thread's four pixels share the column
+    const double a0 = (double)(1.f - fx), a1 = (double)fx;
     for (int k = tid; k < 64 * 16; k += 256) {
         const int dx = dx0 + (k & 63), dy = dy0 + (k >> 6);
         if (dx >= P.W || dy >= P.H) continue;
-        int sx, sy;
-        float fx, fy;
-        psl_lsd_src(dx, P.w, &sx, &fx, true);
+        int sy;
+        float fy;
         psl_lsd_src(dy, P.h, &sy, &fy, false);
-        const double a0 = (double)(1.f - fx), a1 = (double)fx, b0 = (double)(1.f - fy), b1 = (double)fy;
+        const double b0 = (double)(1.f - fy), b1 = (double)fy;
         const int sy0 = min(max(sy, 0), P.h - 1) - by0, sy1 = min(max(sy + 1, 0), P.h - 1) - by0;
         const int cx = sx - bx0;
         double h0, h1;
