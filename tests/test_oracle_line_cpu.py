@@ -94,3 +94,18 @@ def test_line_golden_vectors():
     np.testing.assert_array_equal(oracle_lib.lsd_detect(g["image"]), g["segments"])
     L = np.stack([kls[n] for n in ("startPointX", "startPointY", "endPointX", "endPointY")], 1).astype(np.float32)
     np.testing.assert_array_equal(oracle_lib.lil_pair(L, 20.0, np.float32(np.pi / 4), 640, 480), g["fans"])
+
+
+def test_seed_cos_sin_of_k_lsd_grad_equals_libm_for_every_float_angle(tmp_path):
+    """k_lsd_grad tabulates (float)cos(a), (float)sin(a), a = (double)deg * DEG_TO_RADS, with a restricted-range evaluation
+    (psl-slam_amd/csrc/psl_sincos64.h) instead of the device library's general f64 cos / sin.  oracle/sincos64_check.c runs
+    the same header on the host against libm for all 1 135 869 953 floats in [0, 360] (a few seconds on 8 threads)."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "sincos64_check")
+    subprocess.run(["gcc", "-O2", "-ffp-contract=off", "-mfma", "-o", exe, os.path.join(root, "oracle", "sincos64_check.c"), "-lm", "-lpthread"],
+                   check=True)
+    out = subprocess.run([exe, "8"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout
+    assert "sin mismatches 0, cos mismatches 0" in out.stdout
