@@ -247,21 +247,22 @@ __global__ __launch_bounds__(256) void k_lsd_scale_tiled(LineParams P, const uin
 // region-growing chain needs: cosf((float)a), sinf((float)a) (every pixel that joins a region) and
 // (float)cos(a), (float)sin(a) (the seed pixel), so that the serial chain contains no trigonometry.
 __global__ __launch_bounds__(256) void k_lsd_grad(LineParams P, const double* __restrict__ scaled, float* __restrict__ angdeg,
-                                                   double* __restrict__ modgrad, float4* __restrict__ trig) {
+                                                   double* __restrict__ modgrad, float4* __restrict__ trig, float2* __restrict__ seedt) {
     const int frame = blockIdx.z;
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= P.W || y >= P.H) return;
     const size_t o = (size_t)frame * P.W * P.H + (size_t)y * P.W + x;
-    // trig[] is written (and meaningful) only where the angle is defined: k_lsd_grow3 reads it for every neighbour but uses it
-    // only for pixels with a defined angle; not writing 16 B for the other ~85 % of the pixels halves this kernel's HBM writes
-    if (x == P.W - 1 || y == P.H - 1) { angdeg[o] = PSL_LSD_NOTDEF; modgrad[o] = 0.0; return; }
+    // trig[o] = (cosf, sinf, angle in degrees or NOTDEF, used = 0): everything a round of k_lsd_grow3 needs of a neighbour in ONE
+    // 16-byte record (a round touches 3-4 cache lines instead of ~10 in three arrays: the growing is bound by the latency of these
+    // fetches); seedt[o] = (float)cos / sin of the double angle, read once per seed, written only where the angle is defined.
+    if (x == P.W - 1 || y == P.H - 1) { angdeg[o] = PSL_LSD_NOTDEF; modgrad[o] = 0.0; trig[o] = make_float4(0, 0, PSL_LSD_NOTDEF, 0); return; }
     const double* r0 = scaled + (size_t)frame * P.W * P.H + (size_t)y * P.W;
     const double* r1 = r0 + P.W;
     const double DA = PSL_DSUB(r1[x + 1], r0[x]), BC = PSL_DSUB(r0[x + 1], r1[x]);
     const double gx = PSL_DADD(DA, BC), gy = PSL_DSUB(DA, BC);
     const double norm = __dsqrt_rn(PSL_DADD(PSL_DMUL(gx, gx), PSL_DMUL(gy, gy)) / 4);
     modgrad[o] = norm;
-    if (norm <= P.rho) { angdeg[o] = PSL_LSD_NOTDEF; return; }
+    if (norm <= P.rho) { angdeg[o] = PSL_LSD_NOTDEF; trig[o] = make_float4(0, 0, PSL_LSD_NOTDEF, 0); return; }
     const float deg = psl_fast_atan2((float)gx, (float)(-gy));
     angdeg[o] = deg;
     const double ad = PSL_DMUL((double)deg, PSL_DEG2RAD);
@@ -269,7 +270,8 @@ __global__ __launch_bounds__(256) void k_lsd_grad(LineParams P, const double* __
     psl_sincosf((float)ad, &sn, &cs);
     float cd, sd;  // (float)cos(ad), (float)sin(ad): restricted-range evaluation, pinned exhaustively (psl_sincos64.h)
     psl_cos_sin_2pi_f32(ad, &cd, &sd);
-    trig[o] = make_float4(cs, sn, cd, sd);
+    trig[o] = make_float4(cs, sn, deg, 0);
+    seedt[o] = make_float2(cd, sd);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -506,7 +508,8 @@ struct LsdW {
     int W, H, lane;
     const float* ang;
     const double* mod;
-    const float4* trig;
+    float4* trig;          // (cosf, sinf, degrees | NOTDEF, used flag of k_lsd_grow3) per pixel
+    const float2* seedt;   // (float)cos, (float)sin of the double angle (seed pixels)
     uint32_t* used;   // bitmap in LDS (k_lsd_grow2)
     uint8_t* usedb;   // one byte per pixel in HBM (k_lsd_grow3, gused = true): plain byte stores instead of read-modify-write
     bool gused;
@@ -539,8 +542,8 @@ __device__ int lsdw_region_grow(const LsdW& F, int sx, int sy, double* reg_angle
     const int addr0 = sx + sy * F.W;
     lsdw_push(F, 0, (uint32_t)sx | ((uint32_t)sy << 16));
     double reg_angle = PSL_DMUL((double)F.ang[addr0], PSL_DEG2RAD);
-    const float4 t0 = F.trig[addr0];
-    float sumdx = t0.z, sumdy = t0.w;  // float(cos(reg_angle)), float(sin(reg_angle))
+    const float2 t0 = F.seedt[addr0];
+    float sumdx = t0.x, sumdy = t0.y;  // float(cos(reg_angle)), float(sin(reg_angle))
     lsdw_set(F, addr0);
     const int e = F.lane / 9, k = F.lane - e * 9, ky = k / 3, kx = k - ky * 3;
     // neighbour data of the entries popped in this round (cur) and, software-pipelined, of the entries the
@@ -609,15 +612,15 @@ __device__ int lsdw_region_grow(const LsdW& F, int sx, int sy, double* reg_angle
     return reg_size;
 }
 
-// ---- variant with the `used` map in HBM (L2-resident) ---------------------------------------------------
-// Frees the 24 KB of LDS per wave, so 6 waves per SIMD can overlap their serial chains.  One byte per pixel, written by
-// lane 0 with agent-scope stores and read with agent-scope relaxed loads (L1 bypass); inside a round every lane keeps its own
-// "used" flag, updated by comparing its pixel with each pixel that is added.
+// ---- variant with the `used` flags in HBM ---------------------------------------------------------------
+// Frees the 24 KB of LDS per wave, so 6 waves per SIMD can overlap their serial chains.  The flag is the fourth word of the
+// pixel's 16-byte record, written by lane 0 and read by the same wave only (workgroup scope: the CU's L1 is coherent for its
+// own stores); inside a round every lane keeps its own "used" flag, updated by comparing its pixel with each pixel that is added.
 __device__ __forceinline__ bool lsdg_used(const LsdW& F, int a) {
-    return __hip_atomic_load(&F.usedb[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+    return __hip_atomic_load(reinterpret_cast<const uint32_t*>(&F.trig[a].w), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0;
 }
-__device__ __forceinline__ void lsdg_mark(const LsdW& F, int a, uint8_t v) {
-    __hip_atomic_store(&F.usedb[a], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+__device__ __forceinline__ void lsdg_mark(const LsdW& F, int a, uint32_t v) {
+    __hip_atomic_store(reinterpret_cast<uint32_t*>(&F.trig[a].w), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 // Queue push of k_lsd_grow3: the LDS ring is the queue; a block of 512 entries goes to HBM (coalesced, all lanes) when it is
 // complete, long before the ring wraps over it, so that lsdw_reg finds older entries there.  Called by all lanes.
@@ -636,28 +639,32 @@ __device__ __forceinline__ void lsdg_push(const LsdW& F, int idx, uint32_t v, in
 
 // |theta - ad| folded into [0, pi] and compared with prec, as lsdw_aligned but without branches: both differences are formed
 // and one is selected (the serial acceptance chain below executes this once per accepted pixel).
-__device__ __forceinline__ bool lsdg_aligned(double ad, double theta, double prec) {
+__device__ __forceinline__ double lsdg_fold(double ad, double theta) {
     const double d = __builtin_fabs(PSL_DSUB(theta, ad));
     const double d2 = __builtin_fabs(PSL_DSUB(d, 2 * PSL_PI));
-    return (d > (3 * PSL_PI) / 2 ? d2 : d) <= prec;
+    return d > (3 * PSL_PI) / 2 ? d2 : d;
 }
+__device__ __forceinline__ bool lsdg_aligned(double ad, double theta, double prec) { return lsdg_fold(ad, theta) <= prec; }
+__device__ __forceinline__ double lsdg_angle(float sumdx, float sumdy) { return PSL_DMUL((double)psl_fast_atan2(sumdy, sumdx), PSL_DEG2RAD); }
 
 __device__ int lsdg_region_grow(const LsdW& F, int sx, int sy, double* reg_angle_out, double prec) {
     int reg_size = 1;
     const int addr0 = sx + sy * F.W;
     lsdg_push(F, 0, (uint32_t)sx | ((uint32_t)sy << 16), addr0);
     double reg_angle = PSL_DMUL((double)F.ang[addr0], PSL_DEG2RAD);
-    const float4 t0 = F.trig[addr0];
-    float sumdx = t0.z, sumdy = t0.w;
+    const float2 t0 = F.seedt[addr0];
+    float sumdx = t0.x, sumdy = t0.y;
+    float Mref = fmaxf(__builtin_fabsf(sumdx), __builtin_fabsf(sumdy)), invM = __builtin_amdgcn_rcpf(Mref);
+    int m_prior = 0;  // pixels added since reg_angle was computed from the sums
     const int e = F.lane / 9, k = F.lane - e * 9, ky = k / 3, kx = k - ky * 3;
     int i = 0;
     while (i < reg_size) {
         const int nb = min(7, reg_size - i);
         // A round costs two memory round trips in series if it is written naively: wait for the marks of the previous round,
         // then fetch the neighbours.  The angle and its cosine / sine do not depend on the marks, so they are requested FIRST
-        // (unconditionally: clamped address, so that exactly two vector-memory instructions follow the marks), then
-        // `s_waitcnt vmcnt(2)` - vector-memory operations complete in issue order on gfx9 - waits for everything older than these
-        // two loads, i.e. for every mark issued so far, and only the `used` bytes are read after it.
+        // (unconditionally: clamped address, so that exactly one vector-memory instruction follows the marks), then
+        // `s_waitcnt vmcnt(1)` - vector-memory operations complete in issue order on gfx9 - waits for everything older than that
+        // load, i.e. for every mark issued so far, and only the `used` word of the same record (same cache line) is read after it.
         const bool mine = F.lane < 63 && e < nb;
         const int qe = i + (mine ? e : 0);
         // the queue entry comes from the LDS ring through an explicit LDS pointer: a select between the (generic) ring pointer
@@ -671,36 +678,79 @@ __device__ int lsdg_region_grow(const LsdW& F, int sx, int sy, double* reg_angle
         const int nx = (int)(rp & 0xffff) + kx - 1, ny = (int)(rp >> 16) + ky - 1;
         const bool inside = mine && nx >= 0 && nx < F.W && ny >= 0 && ny < F.H;
         const int cidx = inside ? nx + ny * F.W : addr0;
-        float a = F.ang[cidx];
-        const float2 t = *reinterpret_cast<const float2*>(&F.trig[cidx]);
-        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        const float3 t = *reinterpret_cast<const float3*>(&F.trig[cidx]);
+        asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
         const bool u = lsdg_used(F, cidx) || !inside;
         const float cs = t.x, sn = t.y;
+        float a = t.z;
         const uint32_t xy = inside ? ((uint32_t)nx | ((uint32_t)ny << 16)) : 0xffffffffu;
         if (!inside) a = PSL_LSD_NOTDEF;
         const double ad = PSL_DMUL((double)a, PSL_DEG2RAD);
-        // lanes are ordered (entry, neighbour) exactly as the reference visits them.  `live` = lanes that can still join in this
-        // round: a defined angle, not used, behind the last accepted lane, not a second copy of an accepted pixel.  Take the
-        // first live lane aligned with the CURRENT angle, add it, re-test the rest.
+        // Lanes are ordered (entry, neighbour) exactly as the reference visits them; `live` = lanes that can still join in this
+        // round (defined angle, not used, behind the last decided lane, not a second copy of an accepted pixel).  The reference
+        // updates the region angle after EVERY accepted pixel (fastAtan2 of the running sums, ~37 instructions of a ~45
+        // instruction step) and tests the next neighbour against it.  Here the angle is brought up to date only when a decision
+        // needs it: `reg_angle` is exact for the sums at some earlier moment ("reference"), m_prior pixels have been added since,
+        // and a lane that at most n more live lanes precede is tested against an angle that differs from the reference one by
+        //   <= 2 eps + asin(1.01 (m_prior + n) / |S_ref|) <= 2 eps + 1.6 (m_prior + n) / max(|sumdx|, |sumdy|)_ref
+        // (eps: error of the fastAtan2 polynomial, measured 0.0095 deg, taken as 0.05 deg; unit vectors added to a sum S turn it
+        // by at most asin(|added| / |S|); asin x <= (pi / 2) x; the region's sum never shrinks below 1 because every added vector
+        // is within 22.5 deg of it).  The folded difference is 1-Lipschitz in the angle, so a lane whose difference to the
+        // reference angle is below prec - delta joins, above prec + delta does not, whatever the exact angle is; the first lane
+        // in between stops the batch, the angle is recomputed from the sums (exactly what the reference holds there) and that lane
+        // is decided as before.  Sums are added in lane order, so all results are bit-identical; on clean edges one fastAtan2
+        // serves several pixels.
         unsigned long long live = __ballot(a != PSL_LSD_NOTDEF && !u);
+        if (live && (float)(4 * m_prior) > Mref) {  // keep the drift bound useful
+            reg_angle = lsdg_angle(sumdx, sumdy);
+            Mref = fmaxf(__builtin_fabsf(sumdx), __builtin_fabsf(sumdy)); invM = __builtin_amdgcn_rcpf(Mref); m_prior = 0;
+        }
         while (live) {
-            const unsigned long long m = __ballot(lsdg_aligned(ad, reg_angle, prec)) & live;
-            if (!m) break;
-            const int L = __ffsll((long long)m) - 1;  // wave-uniform: v_readlane instead of ds_bpermute
+            const double r = lsdg_fold(ad, reg_angle);
+            const int nbef = __builtin_amdgcn_mbcnt_hi((uint32_t)(live >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)live, 0u));
+            const float ratio = (float)(m_prior + nbef) * invM;
+            const float delta = ratio <= 0.9f ? (0.002f + 1.6f * ratio) * 1.01f : 10.0f;
+            const unsigned long long RA = __ballot(r <= prec - (double)delta) & live;
+            const unsigned long long RN = __ballot(r >= prec + (double)delta);
+            const unsigned long long amb = live & ~RA & ~RN;
+            const unsigned long long below = amb ? ((amb & (0ull - amb)) - 1ull) : ~0ull;  // lanes in front of the first undecided one
+            unsigned long long acc = RA & below;
+            live &= ~below;
+            while (acc) {
+                const int L = __ffsll((long long)acc) - 1;  // wave-uniform: v_readlane instead of ds_bpermute
+                const uint32_t xyL = (uint32_t)__builtin_amdgcn_readlane((int)xy, L);
+                const int cL = __builtin_amdgcn_readlane(cidx, L);
+                const float csL = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cs), L));
+                const float snL = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sn), L));
+                const unsigned long long dup = __ballot(xy == xyL);  // this lane and the other copies of its pixel
+                acc &= ~dup; live &= ~dup;
+                lsdg_push(F, reg_size, xyL, cL);
+                ++reg_size; ++m_prior;
+                sumdx = PSL_FADD(sumdx, csL);
+                sumdy = PSL_FADD(sumdy, snL);
+            }
+            if (!live) break;
+            if (m_prior) {
+                reg_angle = lsdg_angle(sumdx, sumdy);
+                Mref = fmaxf(__builtin_fabsf(sumdx), __builtin_fabsf(sumdy)); invM = __builtin_amdgcn_rcpf(Mref); m_prior = 0;
+            }
+            const unsigned long long m1 = __ballot(lsdg_aligned(ad, reg_angle, prec)) & live;
+            if (!m1) break;  // the angle is exact and does not change without a new pixel: nobody else joins in this round
+            const int L = __ffsll((long long)m1) - 1;
             const uint32_t xyL = (uint32_t)__builtin_amdgcn_readlane((int)xy, L);
             const int cL = __builtin_amdgcn_readlane(cidx, L);
             const float csL = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cs), L));
             const float snL = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sn), L));
             live &= ~((2ull << L) - 1ull) & ~__ballot(xy == xyL);
             lsdg_push(F, reg_size, xyL, cL);
-            ++reg_size;
+            ++reg_size; m_prior = 1;
             sumdx = PSL_FADD(sumdx, csL);
             sumdy = PSL_FADD(sumdy, snL);
-            reg_angle = PSL_DMUL((double)psl_fast_atan2(sumdy, sumdx), PSL_DEG2RAD);
         }
         i += nb;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (m_prior) reg_angle = lsdg_angle(sumdx, sumdy);
     *reg_angle_out = reg_angle;
     return reg_size;
 }
@@ -874,8 +924,8 @@ __device__ int lsdw_refine(const LsdW& F, int reg_size, double reg_angle, double
 }
 
 __global__ __launch_bounds__(64) void k_lsd_grow2(LineParams P, const float* __restrict__ angdeg, const double* __restrict__ modgrad,
-                                                   const float4* __restrict__ trig, uint32_t* __restrict__ reg, float* __restrict__ seg,
-                                                   int* __restrict__ nseg) {
+                                                   float4* __restrict__ trig, const float2* __restrict__ seedt, uint32_t* __restrict__ reg,
+                                                   float* __restrict__ seg, int* __restrict__ nseg) {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];  // used bitmap
     __shared__ uint32_t s_ring[PSL_LSD_RING];
     __shared__ double s_term[3 * 64];
@@ -885,7 +935,7 @@ __global__ __launch_bounds__(64) void k_lsd_grow2(LineParams P, const float* __r
     LsdW F;
     F.W = P.W; F.H = P.H; F.lane = lane;
     F.ang = angdeg + frame * npx; F.mod = modgrad + frame * npx; F.trig = trig + frame * npx; F.reg = reg + frame * npx;
-    F.used = s_dyn; F.gused = false; F.ring = s_ring; F.term = s_term;
+    F.used = s_dyn; F.usedb = nullptr; F.seedt = seedt + frame * npx; F.gused = false; F.ring = s_ring; F.term = s_term;
     for (int i = lane; i < words; i += 64) F.used[i] = 0;
     __builtin_amdgcn_wave_barrier();
     float* out = seg + (size_t)frame * P.maxseg * 4;
@@ -938,7 +988,7 @@ __global__ __launch_bounds__(64) void k_lsd_grow2(LineParams P, const float* __r
                            // 9 % faster per frame than 5 with 4096-5120; 7 (72 VGPRs, 18 spills) gains nothing more
 #endif
 __global__ __launch_bounds__(64, PSL_GROW_WAVES) void k_lsd_grow3(LineParams P, const float* __restrict__ angdeg, const double* __restrict__ modgrad,
-                                                   const float4* __restrict__ trig, uint8_t* __restrict__ usedmap, uint32_t* __restrict__ reg,
+                                                   float4* __restrict__ trig, const float2* __restrict__ seedt, uint32_t* __restrict__ reg,
                                                    float* __restrict__ seg, int* __restrict__ nseg) {
     __shared__ uint32_t s_ring[PSL_LSD_RING];
     __shared__ double s_term[3 * 64];
@@ -948,17 +998,9 @@ __global__ __launch_bounds__(64, PSL_GROW_WAVES) void k_lsd_grow3(LineParams P, 
     LsdW F;
     F.W = P.W; F.H = P.H; F.lane = lane;
     F.ang = angdeg + frame * npx; F.mod = modgrad + frame * npx; F.trig = trig + frame * npx; F.reg = reg + frame * npx;
-    F.used = nullptr; F.usedb = usedmap + (size_t)frame * npx; F.gused = true; F.ring = s_ring; F.term = s_term;
-    {   // npx is a multiple of 4 or the tail is cleared bytewise; the frame's map starts 4-aligned when npx % 4 == 0
-        const size_t head = (4 - ((size_t)F.usedb & 3)) & 3;
-        uint32_t* w = reinterpret_cast<uint32_t*>(F.usedb + head);
-        const size_t nw = (npx - head) >> 2;
-        for (size_t i = lane; i < nw; i += 64) __hip_atomic_store(&w[i], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if ((size_t)lane < head) lsdg_mark(F, lane, 0);
-        for (size_t i = head + (nw << 2) + lane; i < npx; i += 64) lsdg_mark(F, (int)i, 0);
-    }
+    F.used = nullptr; F.usedb = nullptr; F.seedt = seedt + frame * npx; F.gused = true; F.ring = s_ring; F.term = s_term;
+    // (the used flags start at 0: k_lsd_grad has just written the records)
     (void)words;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     float* out = seg + (size_t)frame * P.maxseg * 4;
     int count = 0;
     const int scan_end = (P.H - 1) * P.W;

@@ -28,6 +28,7 @@ struct pslfe_line {
     float* d_angdeg = nullptr;
     double* d_modgrad = nullptr;
     float4* d_trig = nullptr;
+    float2* d_seedt = nullptr;
     uint8_t* d_used = nullptr;
     uint32_t* d_usedbits = nullptr;
     uint32_t* d_reg = nullptr;
@@ -55,6 +56,7 @@ struct pslfe_line {
         d_kls = nullptr; d_ldesc = nullptr; d_fdesc = nullptr; d_lineEq = nullptr; d_nkl = nullptr; d_status = nullptr; d_dxy = nullptr;
         d_rawfans = nullptr; d_fans = nullptr; d_nfans = nullptr; d_tmplines = nullptr;
         hipFree(d_trig); d_trig = nullptr;
+        hipFree(d_seedt); d_seedt = nullptr;
         hipFree(d_usedbits); d_usedbits = nullptr;
         hipFree(d_in); hipFree(d_scaled); hipFree(d_angdeg); hipFree(d_modgrad); hipFree(d_used); hipFree(d_reg);
         hipFree(d_seg); hipFree(d_nseg);
@@ -113,6 +115,7 @@ struct pslfe_line {
         PSL_HIP(hipMalloc((void**)&d_angdeg, npx * F * sizeof(float)));
         PSL_HIP(hipMalloc((void**)&d_modgrad, npx * F * sizeof(double)));
         PSL_HIP(hipMalloc((void**)&d_trig, npx * F * sizeof(float4)));
+        PSL_HIP(hipMalloc((void**)&d_seedt, npx * F * sizeof(float2)));
         PSL_HIP(hipMalloc((void**)&d_used, npx * F));
         PSL_HIP(hipMalloc((void**)&d_reg, npx * F * sizeof(uint32_t)));
         PSL_HIP(hipMalloc((void**)&d_seg, (size_t)Q.maxseg * 4 * sizeof(float) * F));
@@ -170,7 +173,7 @@ struct pslfe_line {
         }
         {
             PSL_STAGE_BEGIN(ctx, "line.lsd_grad");
-            k_lsd_grad<<<grid, 256, 0, st>>>(P, d_scaled, d_angdeg, d_modgrad, d_trig);
+            k_lsd_grad<<<grid, 256, 0, st>>>(P, d_scaled, d_angdeg, d_modgrad, d_trig, d_seedt);
             PSL_STAGE_END(ctx, "line.lsd_grad");
         }
         {
@@ -178,10 +181,10 @@ struct pslfe_line {
             const size_t lds = (((size_t)P.W * P.H + 31) / 32) * sizeof(uint32_t);
             const char* variant = getenv("PSLFE_LSD_GROW");  // "serial" | "lds" | default: HBM bitmap, many waves per SIMD
             if (!variant || (strcmp(variant, "serial") != 0 && strcmp(variant, "lds") != 0)) {
-                k_lsd_grow3<<<F, 64, 0, st>>>(P, d_angdeg, d_modgrad, d_trig, d_used, d_reg, d_seg, d_nseg);
+                k_lsd_grow3<<<F, 64, 0, st>>>(P, d_angdeg, d_modgrad, d_trig, d_seedt, d_reg, d_seg, d_nseg);
             } else if (lds <= 140 * 1024 && strcmp(variant, "lds") == 0) {
                 if (lds > 48 * 1024) PSL_HIP(hipFuncSetAttribute((const void*)k_lsd_grow2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                k_lsd_grow2<<<F, 64, lds, st>>>(P, d_angdeg, d_modgrad, d_trig, d_reg, d_seg, d_nseg);
+                k_lsd_grow2<<<F, 64, lds, st>>>(P, d_angdeg, d_modgrad, d_trig, d_seedt, d_reg, d_seg, d_nseg);
             } else {
                 k_lsd_grow<<<F, 64, 0, st>>>(P, d_angdeg, d_modgrad, d_used, d_reg, d_seg, d_nseg);
             }
