@@ -32,6 +32,7 @@ struct LineParams {
     double gk[7];             // Gaussian kernel sigma 0.75 (f64)
     double rho, prec, p;      // gradient threshold, angle tolerance (rad), p = ANG_TH/180
     int min_reg_size;
+    int full_grad;            // k_lsd_grad stores the gradient magnitude of every pixel (debug tap), not only where the angle is defined
     int lbdK[5];              // integer Gaussian 5x5 sigma 1 (OpenCV 3.2 8-bit path)
     float gaussG[63], gaussL[21];
 };
@@ -255,14 +256,23 @@ __global__ __launch_bounds__(256) void k_lsd_grad(LineParams P, const double* __
     // trig[o] = (cosf, sinf, angle in degrees or NOTDEF, used = 0): everything a round of k_lsd_grow3 needs of a neighbour in ONE
     // 16-byte record (a round touches 3-4 cache lines instead of ~10 in three arrays: the growing is bound by the latency of these
     // fetches); seedt[o] = (float)cos / sin of the double angle, read once per seed, written only where the angle is defined.
-    if (x == P.W - 1 || y == P.H - 1) { angdeg[o] = PSL_LSD_NOTDEF; modgrad[o] = 0.0; trig[o] = make_float4(0, 0, PSL_LSD_NOTDEF, 0); return; }
+    if (x == P.W - 1 || y == P.H - 1) {
+        angdeg[o] = PSL_LSD_NOTDEF; trig[o] = make_float4(0, 0, PSL_LSD_NOTDEF, 0);
+        if (P.full_grad) modgrad[o] = 0.0;
+        return;
+    }
     const double* r0 = scaled + (size_t)frame * P.W * P.H + (size_t)y * P.W;
     const double* r1 = r0 + P.W;
     const double DA = PSL_DSUB(r1[x + 1], r0[x]), BC = PSL_DSUB(r0[x + 1], r1[x]);
     const double gx = PSL_DADD(DA, BC), gy = PSL_DSUB(DA, BC);
     const double norm = __dsqrt_rn(PSL_DADD(PSL_DMUL(gx, gx), PSL_DMUL(gy, gy)) / 4);
+    // the magnitude is read back only for pixels of regions (defined angle): many-frames launches skip the other ~85 % of the stores
+    if (norm <= P.rho) {
+        angdeg[o] = PSL_LSD_NOTDEF; trig[o] = make_float4(0, 0, PSL_LSD_NOTDEF, 0);
+        if (P.full_grad) modgrad[o] = norm;
+        return;
+    }
     modgrad[o] = norm;
-    if (norm <= P.rho) { angdeg[o] = PSL_LSD_NOTDEF; trig[o] = make_float4(0, 0, PSL_LSD_NOTDEF, 0); return; }
     const float deg = psl_fast_atan2((float)gx, (float)(-gy));
     angdeg[o] = deg;
     const double ad = PSL_DMUL((double)deg, PSL_DEG2RAD);
@@ -645,6 +655,11 @@ __device__ __forceinline__ double lsdg_fold(double ad, double theta) {
     return d > (3 * PSL_PI) / 2 ? d2 : d;
 }
 __device__ __forceinline__ bool lsdg_aligned(double ad, double theta, double prec) { return lsdg_fold(ad, theta) <= prec; }
+// a lower bound of |(x, y)|: its projection on the direction pi/8 from the larger component (constants rounded down)
+__device__ __forceinline__ float lsdg_norm_lb(float x, float y) {
+    const float ax = __builtin_fabsf(x), ay = __builtin_fabsf(y);
+    return 0.9238f * fmaxf(ax, ay) + 0.3826f * fminf(ax, ay);
+}
 __device__ __forceinline__ double lsdg_angle(float sumdx, float sumdy) { return PSL_DMUL((double)psl_fast_atan2(sumdy, sumdx), PSL_DEG2RAD); }
 
 __device__ int lsdg_region_grow(const LsdW& F, int sx, int sy, double* reg_angle_out, double prec) {
@@ -654,7 +669,7 @@ __device__ int lsdg_region_grow(const LsdW& F, int sx, int sy, double* reg_angle
     double reg_angle = PSL_DMUL((double)F.ang[addr0], PSL_DEG2RAD);
     const float2 t0 = F.seedt[addr0];
     float sumdx = t0.x, sumdy = t0.y;
-    float Mref = fmaxf(__builtin_fabsf(sumdx), __builtin_fabsf(sumdy)), invM = __builtin_amdgcn_rcpf(Mref);
+    float Mref = lsdg_norm_lb(sumdx, sumdy), invM = __builtin_amdgcn_rcpf(Mref);
     int m_prior = 0;  // pixels added since reg_angle was computed from the sums
     const int e = F.lane / 9, k = F.lane - e * 9, ky = k / 3, kx = k - ky * 3;
     int i = 0;
@@ -692,9 +707,10 @@ __device__ int lsdg_region_grow(const LsdW& F, int sx, int sy, double* reg_angle
         // instruction step) and tests the next neighbour against it.  Here the angle is brought up to date only when a decision
         // needs it: `reg_angle` is exact for the sums at some earlier moment ("reference"), m_prior pixels have been added since,
         // and a lane that at most n more live lanes precede is tested against an angle that differs from the reference one by
-        //   <= 2 eps + asin(1.01 (m_prior + n) / |S_ref|) <= 2 eps + 1.6 (m_prior + n) / max(|sumdx|, |sumdy|)_ref
+        //   <= 2 eps + asin(x), x = 1.01 (m_prior + n) / |S_ref|;  asin x <= 1.048 x for x <= 0.5, <= (pi / 2) x always;
+        //   |S_ref| >= 0.9238 max(|sumdx|, |sumdy|) + 0.3826 min(|sumdx|, |sumdy|) (its projection on the direction pi / 8)
         // (eps: error of the fastAtan2 polynomial, measured 0.0095 deg, taken as 0.05 deg; unit vectors added to a sum S turn it
-        // by at most asin(|added| / |S|); asin x <= (pi / 2) x; the region's sum never shrinks below 1 because every added vector
+        // by at most asin(|added| / |S|); the region's sum never shrinks below 1 because every added vector
         // is within 22.5 deg of it).  The folded difference is 1-Lipschitz in the angle, so a lane whose difference to the
         // reference angle is below prec - delta joins, above prec + delta does not, whatever the exact angle is; the first lane
         // in between stops the batch, the angle is recomputed from the sums (exactly what the reference holds there) and that lane
@@ -703,13 +719,13 @@ __device__ int lsdg_region_grow(const LsdW& F, int sx, int sy, double* reg_angle
         unsigned long long live = __ballot(a != PSL_LSD_NOTDEF && !u);
         if (live && (float)(4 * m_prior) > Mref) {  // keep the drift bound useful
             reg_angle = lsdg_angle(sumdx, sumdy);
-            Mref = fmaxf(__builtin_fabsf(sumdx), __builtin_fabsf(sumdy)); invM = __builtin_amdgcn_rcpf(Mref); m_prior = 0;
+            Mref = lsdg_norm_lb(sumdx, sumdy); invM = __builtin_amdgcn_rcpf(Mref); m_prior = 0;
         }
         while (live) {
             const double r = lsdg_fold(ad, reg_angle);
             const int nbef = __builtin_amdgcn_mbcnt_hi((uint32_t)(live >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)live, 0u));
             const float ratio = (float)(m_prior + nbef) * invM;
-            const float delta = ratio <= 0.9f ? (0.002f + 1.6f * ratio) * 1.01f : 10.0f;
+            const float delta = ratio <= 0.49f ? (0.002f + 1.06f * ratio) * 1.01f : (ratio <= 0.9f ? (0.002f + 1.6f * ratio) * 1.01f : 10.0f);
             const unsigned long long RA = __ballot(r <= prec - (double)delta) & live;
             const unsigned long long RN = __ballot(r >= prec + (double)delta);
             const unsigned long long amb = live & ~RA & ~RN;
@@ -732,7 +748,7 @@ __device__ int lsdg_region_grow(const LsdW& F, int sx, int sy, double* reg_angle
             if (!live) break;
             if (m_prior) {
                 reg_angle = lsdg_angle(sumdx, sumdy);
-                Mref = fmaxf(__builtin_fabsf(sumdx), __builtin_fabsf(sumdy)); invM = __builtin_amdgcn_rcpf(Mref); m_prior = 0;
+                Mref = lsdg_norm_lb(sumdx, sumdy); invM = __builtin_amdgcn_rcpf(Mref); m_prior = 0;
             }
             const unsigned long long m1 = __ballot(lsdg_aligned(ad, reg_angle, prec)) & live;
             if (!m1) break;  // the angle is exact and does not change without a new pixel: nobody else joins in this round
