@@ -247,41 +247,92 @@ __global__ __launch_bounds__(256) void k_lsd_scale_tiled(LineParams P, const uin
 // Also tabulates, per pixel with a defined angle a = (double)deg * DEG_TO_RADS, the four values the
 // region-growing chain needs: cosf((float)a), sinf((float)a) (every pixel that joins a region) and
 // (float)cos(a), (float)sin(a) (the seed pixel), so that the serial chain contains no trigonometry.
-__global__ __launch_bounds__(256) void k_lsd_grad(LineParams P, const double* __restrict__ scaled, float* __restrict__ angdeg,
-                                                   double* __restrict__ modgrad, float4* __restrict__ trig, float2* __restrict__ seedt) {
-    const int frame = blockIdx.z;
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= P.W || y >= P.H) return;
-    const size_t o = (size_t)frame * P.W * P.H + (size_t)y * P.W + x;
-    // trig[o] = (cosf, sinf, angle in degrees or NOTDEF, used = 0): everything a round of k_lsd_grow3 needs of a neighbour in ONE
-    // 16-byte record (a round touches 3-4 cache lines instead of ~10 in three arrays: the growing is bound by the latency of these
-    // fetches); seedt[o] = (float)cos / sin of the double angle, read once per seed, written only where the angle is defined.
-    if (x == P.W - 1 || y == P.H - 1) {
-        angdeg[o] = PSL_LSD_NOTDEF; trig[o] = make_float4(0, 0, PSL_LSD_NOTDEF, 0);
-        if (P.full_grad) modgrad[o] = 0.0;
-        return;
-    }
-    const double* r0 = scaled + (size_t)frame * P.W * P.H + (size_t)y * P.W;
+#define PSL_GRAD_TH 16  // tile height of k_lsd_grad (64 x 16 pixels per workgroup, 4 per thread)
+// gradient magnitude of pixel (x, y) and its components; false where the reference leaves the angle undefined by construction
+__device__ __forceinline__ bool psl_lsd_norm(const LineParams& P, const double* __restrict__ img, int x, int y, double* norm, double* gx_, double* gy_) {
+    if (x < 0 || y < 0 || x >= P.W - 1 || y >= P.H - 1) return false;
+    const double* r0 = img + (size_t)y * P.W;
     const double* r1 = r0 + P.W;
     const double DA = PSL_DSUB(r1[x + 1], r0[x]), BC = PSL_DSUB(r0[x + 1], r1[x]);
     const double gx = PSL_DADD(DA, BC), gy = PSL_DSUB(DA, BC);
-    const double norm = __dsqrt_rn(PSL_DADD(PSL_DMUL(gx, gx), PSL_DMUL(gy, gy)) / 4);
-    // the magnitude is read back only for pixels of regions (defined angle): many-frames launches skip the other ~85 % of the stores
-    if (norm <= P.rho) {
-        angdeg[o] = PSL_LSD_NOTDEF; trig[o] = make_float4(0, 0, PSL_LSD_NOTDEF, 0);
-        if (P.full_grad) modgrad[o] = norm;
-        return;
+    *norm = __dsqrt_rn(PSL_DADD(PSL_DMUL(gx, gx), PSL_DMUL(gy, gy)) / 4);
+    *gx_ = gx; *gy_ = gy;
+    return true;
+}
+
+// trig[o] = (cosf, sinf, angle in degrees | NOTDEF, used = 0): everything a round of k_lsd_grow3 needs of a neighbour in ONE
+// 16-byte record (a round touches 3-4 cache lines instead of ~10 in three arrays: the growing is bound by the latency of these
+// fetches); seedt[o] = (float)cos / sin of the double angle, read once per seed.  A record is only ever read for a pixel with a
+// defined angle (seed scan) or for a neighbour of one (growing), so it is written only for those - about a third of the pixels;
+// 16 B for every pixel made this kernel HBM-write-bound (9.4 - 11.5 ms, varying between runs).  Which pixels have a defined
+// neighbour is known from a flag tile in LDS: 64 x 16 pixels per workgroup plus a one-pixel ring whose magnitudes are recomputed.
+__global__ __launch_bounds__(256) void k_lsd_grad(LineParams P, const double* __restrict__ scaled, float* __restrict__ angdeg,
+                                                   double* __restrict__ modgrad, float4* __restrict__ trig, float2* __restrict__ seedt) {
+    __shared__ uint8_t s_def[PSL_GRAD_TH + 2][68];
+    const int frame = blockIdx.z, tid = threadIdx.x;
+    const int x0 = blockIdx.x * 64, y0 = blockIdx.y * PSL_GRAD_TH;
+    const int tx = tid & 63, ty = tid >> 6, x = x0 + tx;
+    const size_t fo = (size_t)frame * P.W * P.H;
+    const double* img = scaled + fo;
+    float cs[4], sn[4], dg[4];
+    // all sixteen loads of the thread's four pixels first (clamped addresses), then the arithmetic: one memory round trip
+    double w00[4], w01[4], w10[4], w11[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int yy = min(y0 + ty + 4 * i, P.H - 2), xx = min(x, P.W - 2);
+        const double* r0 = img + (size_t)yy * P.W + xx;
+        w00[i] = r0[0]; w01[i] = r0[1]; w10[i] = r0[P.W]; w11[i] = r0[P.W + 1];
     }
-    modgrad[o] = norm;
-    const float deg = psl_fast_atan2((float)gx, (float)(-gy));
-    angdeg[o] = deg;
-    const double ad = PSL_DMUL((double)deg, PSL_DEG2RAD);
-    float sn, cs;
-    psl_sincosf((float)ad, &sn, &cs);
-    float cd, sd;  // (float)cos(ad), (float)sin(ad): restricted-range evaluation, pinned exhaustively (psl_sincos64.h)
-    psl_cos_sin_2pi_f32(ad, &cd, &sd);
-    trig[o] = make_float4(cs, sn, deg, 0);
-    seedt[o] = make_float2(cd, sd);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = ty + 4 * i, y = y0 + r;
+        bool def = false;
+        dg[i] = PSL_LSD_NOTDEF; cs[i] = 0.f; sn[i] = 0.f;
+        if (x < P.W && y < P.H) {
+            const size_t o = fo + (size_t)y * P.W + x;
+            double norm = 0.0, gx = 0.0, gy = 0.0;
+            const bool inner = x < P.W - 1 && y < P.H - 1;  // last column / row: magnitude 0, angle undefined by construction
+            if (inner) {
+                const double DA = PSL_DSUB(w11[i], w00[i]), BC = PSL_DSUB(w01[i], w10[i]);
+                gx = PSL_DADD(DA, BC); gy = PSL_DSUB(DA, BC);
+                norm = __dsqrt_rn(PSL_DADD(PSL_DMUL(gx, gx), PSL_DMUL(gy, gy)) / 4);
+            }
+            def = inner && !(norm <= P.rho);
+            // the magnitude is read back only for pixels of regions (defined angle): many-frames launches skip the other stores
+            if (def || P.full_grad) modgrad[o] = norm;
+            if (def) {
+                const float deg = psl_fast_atan2((float)gx, (float)(-gy));
+                const double ad = PSL_DMUL((double)deg, PSL_DEG2RAD);
+                psl_sincosf((float)ad, &sn[i], &cs[i]);
+                float cd, sd;  // (float)cos(ad), (float)sin(ad): restricted-range evaluation, pinned exhaustively (psl_sincos64.h)
+                psl_cos_sin_2pi_f32(ad, &cd, &sd);
+                seedt[o] = make_float2(cd, sd);
+                dg[i] = deg;
+            }
+            angdeg[o] = dg[i];
+        }
+        s_def[r + 1][tx + 1] = def;
+    }
+    // the ring around the tile: 2 x 66 + 2 x 16 = 164 pixels
+    if (tid < 2 * 66 + 2 * PSL_GRAD_TH) {
+        int r, c;
+        if (tid < 132) { r = tid < 66 ? 0 : PSL_GRAD_TH + 1; c = tid < 66 ? tid : tid - 66; }
+        else { const int k = tid - 132; r = 1 + (k >> 1); c = (k & 1) ? 65 : 0; }
+        double norm = 0.0, gx, gy;
+        const bool inner = psl_lsd_norm(P, img, x0 - 1 + c, y0 - 1 + r, &norm, &gx, &gy);
+        s_def[r][c] = inner && !(norm <= P.rho);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = ty + 4 * i, y = y0 + r;
+        if (x >= P.W || y >= P.H) continue;
+        const uint8_t* d0 = &s_def[r][tx];
+        const uint8_t* d1 = &s_def[r + 1][tx];
+        const uint8_t* d2 = &s_def[r + 2][tx];
+        const bool any = (d0[0] | d0[1] | d0[2] | d1[0] | d1[1] | d1[2] | d2[0] | d2[1] | d2[2]) != 0;
+        if (any) trig[fo + (size_t)y * P.W + x] = make_float4(cs[i], sn[i], dg[i], 0);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -174,7 +174,7 @@ struct pslfe_line {
         {
             PSL_STAGE_BEGIN(ctx, "line.lsd_grad");
             P.full_grad = nframes == 1;  // pslfe_line_debug_gradient reads the whole magnitude image of a single-frame call
-            k_lsd_grad<<<grid, 256, 0, st>>>(P, d_scaled, d_angdeg, d_modgrad, d_trig, d_seedt);
+            k_lsd_grad<<<dim3((P.W + 63) / 64, (P.H + PSL_GRAD_TH - 1) / PSL_GRAD_TH, F), 256, 0, st>>>(P, d_scaled, d_angdeg, d_modgrad, d_trig, d_seedt);
             PSL_STAGE_END(ctx, "line.lsd_grad");
         }
         {
