@@ -31,6 +31,7 @@ struct LineParams {
     int nfeatures;            // nLSDFeature (top-N by response)
     double gk[7];             // Gaussian kernel sigma 0.75 (f64)
     double rho, prec, p;      // gradient threshold, angle tolerance (rad), p = ANG_TH/180
+    double rho_q;             // largest q with sqrt(q) <= rho: `norm <= rho` decided on the squared magnitude
     int min_reg_size;
     int full_grad;            // k_lsd_grad stores the gradient magnitude of every pixel (debug tap), not only where the angle is defined
     int lbdK[5];              // integer Gaussian 5x5 sigma 1 (OpenCV 3.2 8-bit path)
@@ -248,15 +249,14 @@ __global__ __launch_bounds__(256) void k_lsd_scale_tiled(LineParams P, const uin
 // region-growing chain needs: cosf((float)a), sinf((float)a) (every pixel that joins a region) and
 // (float)cos(a), (float)sin(a) (the seed pixel), so that the serial chain contains no trigonometry.
 #define PSL_GRAD_TH 16  // tile height of k_lsd_grad (64 x 16 pixels per workgroup, 4 per thread)
-// gradient magnitude of pixel (x, y) and its components; false where the reference leaves the angle undefined by construction
-__device__ __forceinline__ bool psl_lsd_norm(const LineParams& P, const double* __restrict__ img, int x, int y, double* norm, double* gx_, double* gy_) {
+// squared gradient magnitude of pixel (x, y); false where the reference leaves the angle undefined by construction
+__device__ __forceinline__ bool psl_lsd_norm(const LineParams& P, const double* __restrict__ img, int x, int y, double* q) {
     if (x < 0 || y < 0 || x >= P.W - 1 || y >= P.H - 1) return false;
     const double* r0 = img + (size_t)y * P.W;
     const double* r1 = r0 + P.W;
     const double DA = PSL_DSUB(r1[x + 1], r0[x]), BC = PSL_DSUB(r0[x + 1], r1[x]);
     const double gx = PSL_DADD(DA, BC), gy = PSL_DSUB(DA, BC);
-    *norm = __dsqrt_rn(PSL_DADD(PSL_DMUL(gx, gx), PSL_DMUL(gy, gy)) / 4);
-    *gx_ = gx; *gy_ = gy;
+    *q = PSL_DADD(PSL_DMUL(gx, gx), PSL_DMUL(gy, gy)) / 4;
     return true;
 }
 
@@ -292,14 +292,17 @@ __global__ __launch_bounds__(256) void k_lsd_grad(LineParams P, const double* __
             const size_t o = fo + (size_t)y * P.W + x;
             double norm = 0.0, gx = 0.0, gy = 0.0;
             const bool inner = x < P.W - 1 && y < P.H - 1;  // last column / row: magnitude 0, angle undefined by construction
+            double q = 0.0;
             if (inner) {
                 const double DA = PSL_DSUB(w11[i], w00[i]), BC = PSL_DSUB(w01[i], w10[i]);
                 gx = PSL_DADD(DA, BC); gy = PSL_DSUB(DA, BC);
-                norm = __dsqrt_rn(PSL_DADD(PSL_DMUL(gx, gx), PSL_DMUL(gy, gy)) / 4);
+                q = PSL_DADD(PSL_DMUL(gx, gx), PSL_DMUL(gy, gy)) / 4;
             }
-            def = inner && !(norm <= P.rho);
-            // the magnitude is read back only for pixels of regions (defined angle): many-frames launches skip the other stores
-            if (def || P.full_grad) modgrad[o] = norm;
+            // norm = sqrt(q) <= rho  <=>  q <= rho_q (the square root is correctly rounded, hence monotone): the ~85 % of the
+            // pixels below the threshold need no square root.  The magnitude is read back only for pixels of regions (defined
+            // angle): many-frames launches skip the other stores.
+            def = inner && !(q <= P.rho_q);
+            if (def || P.full_grad) { norm = __dsqrt_rn(q); modgrad[o] = norm; }
             if (def) {
                 const float deg = psl_fast_atan2((float)gx, (float)(-gy));
                 const double ad = PSL_DMUL((double)deg, PSL_DEG2RAD);
@@ -318,9 +321,9 @@ __global__ __launch_bounds__(256) void k_lsd_grad(LineParams P, const double* __
         int r, c;
         if (tid < 132) { r = tid < 66 ? 0 : PSL_GRAD_TH + 1; c = tid < 66 ? tid : tid - 66; }
         else { const int k = tid - 132; r = 1 + (k >> 1); c = (k & 1) ? 65 : 0; }
-        double norm = 0.0, gx, gy;
-        const bool inner = psl_lsd_norm(P, img, x0 - 1 + c, y0 - 1 + r, &norm, &gx, &gy);
-        s_def[r][c] = inner && !(norm <= P.rho);
+        double q = 0.0;
+        const bool inner = psl_lsd_norm(P, img, x0 - 1 + c, y0 - 1 + r, &q);
+        s_def[r][c] = inner && !(q <= P.rho_q);
     }
     __syncthreads();
 #pragma unroll

@@ -88,6 +88,13 @@ struct pslfe_line {
         Q.prec = PSL_PI * 22.5 / 180;
         Q.p = 22.5 / 180;
         Q.rho = 2.0 / sin(Q.prec);
+        {   // largest q with sqrt(q) <= rho (sqrt correctly rounded and monotone, on the host as on the device): the
+            // gradient threshold can then be decided on the squared magnitude, without a square root
+            double q = Q.rho * Q.rho;
+            while (sqrt(nextafter(q, INFINITY)) <= Q.rho) q = nextafter(q, INFINITY);
+            while (sqrt(q) > Q.rho) q = nextafter(q, 0.0);
+            Q.rho_q = q;
+        }
         const double LOG_NT = 5 * (log10((double)Q.W) + log10((double)Q.H)) / 2 + log10(11.0);
         Q.min_reg_size = (int)(size_t)(-LOG_NT / log10(Q.p));
         {   // 8-bit GaussianBlur 5x5 sigma 1 -> integer kernel (OpenCV 3.2)
