@@ -761,7 +761,9 @@ __device__ int lsdg_region_grow(const LsdW& F, int sx, int sy, double* reg_angle
         // instruction step) and tests the next neighbour against it.  Here the angle is brought up to date only when a decision
         // needs it: `reg_angle` is exact for the sums at some earlier moment ("reference"), m_prior pixels have been added since,
         // and a lane that at most n more live lanes precede is tested against an angle that differs from the reference one by
-        //   <= 2 eps + asin(x), x = 1.01 (m_prior + n) / |S_ref|;  asin x <= 1.048 x for x <= 0.5, <= (pi / 2) x always;
+        //   <= 2 eps + asin(x), x = 1.012 (m_prior + n) / |S_ref|;  asin x <= 1.048 x for x <= 0.5, <= (pi / 2) x always
+        //   (1.012: the added vectors have length 1 +- 2e-7 and every f32 addition to a sum of norm <= 2e5 rounds by <= 0.012);
+        //   the code uses 1.07 and 1.616 times (m_prior + n) / |S_ref|'s lower bound, i.e. 1 % beyond 1.048 * 1.012 and pi / 2 * 1.012;
         //   |S_ref| >= 0.9238 max(|sumdx|, |sumdy|) + 0.3826 min(|sumdx|, |sumdy|) (its projection on the direction pi / 8)
         // (eps: error of the fastAtan2 polynomial, measured 0.0095 deg, taken as 0.05 deg; unit vectors added to a sum S turn it
         // by at most asin(|added| / |S|); the region's sum never shrinks below 1 because every added vector
