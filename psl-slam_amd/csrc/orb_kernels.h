@@ -121,13 +121,14 @@ __global__ __launch_bounds__(256) void k_pyr_resize(OrbParams P, FrameSrc S, int
 // loads; the taps of a thread then come from LDS instead of scattered byte loads from HBM/L2.  A thread makes
 // 4 adjacent pixels of two rows (16 apart), sharing the column tables; all table loads are issued before the
 // tile loads so that the workgroup pays two memory round trips, not three.
+typedef unsigned short pyr_u16x2 __attribute__((ext_vector_type(2)));
 #define PSL_PYR_TD 36   // tile pitch in dwords
 #define PSL_PYR_TR 48   // tile rows
 #define PSL_PYR_BH 32   // block height
 __global__ __launch_bounds__(256) void k_pyr_resize_tiled(OrbParams P, FrameSrc S, int level,
                                                            const int* __restrict__ xofs, const short2* __restrict__ alpha,
                                                            const int* __restrict__ yofs, const short2* __restrict__ beta) {
-    __shared__ uint32_t s_tile[PSL_PYR_TR * PSL_PYR_TD];
+    __shared__ uint32_t s_tile[PSL_PYR_TR * PSL_PYR_TD + 4];  // + 4: the three-dword reads below may run past the last row
     const OrbLevelP L = P.lv[level];
     const int tid = threadIdx.x;
     int item, frame;
@@ -148,6 +149,7 @@ __global__ __launch_bounds__(256) void k_pyr_resize_tiled(OrbParams P, FrameSrc 
         dx = dx < L.w ? dx : L.w - 1;  // padding columns repeat the last pixel
         sx[j] = xofs[dx];
         a[j] = alpha[dx];
+        if (sx[j] + 1 >= P.lv[level - 1].w) a[j] = make_short2(2048, 0);  // clamped last column: h = p * 2048 (cv::resize)
     }
     int sy0[2], sy1[2];
     short2 b[2];
@@ -177,13 +179,38 @@ __global__ __launch_bounds__(256) void k_pyr_resize_tiled(OrbParams P, FrameSrc 
     }
     __syncthreads();
     if (x4 >= L.pitch) return;
+    // byte offsets of the four left taps inside the three dwords that start at this thread's first tap
+    const int d0 = (sx[0] - cbase) >> 2;
+    int ofs[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) ofs[j] = sx[j] - cbase - 4 * d0;
+    const bool fits = ofs[0] >= 0 && ofs[1] >= ofs[0] && ofs[2] >= ofs[1] && ofs[3] >= ofs[2] && ofs[3] <= 7;  // scale factors up to ~1.3
 #pragma unroll
     for (int rr = 0; rr < 2; ++rr) {
         const int dy = y0 + (tid >> 4) + 16 * rr;
         if (dy >= L.h) break;
         uint8_t* dst = S.pyr + (size_t)frame * S.pyr_fstride + L.img_off + (size_t)dy * L.pitch;
         uint32_t packed = 0;
-        if (staged) {
+        if (staged && fits) {
+            // The eight taps of a source row (4 pixels x 2 columns) lie within 12 bytes: three aligned dwords per source row
+            // instead of eight byte reads (the kernel was bound by LDS instructions), a tap pair is cut out with v_alignbyte,
+            // spread to 16-bit lanes with v_perm and weighted with one v_dot2_u32_u16.
+            const uint32_t* q0 = s_tile + (sy0[rr] - rfirst) * PSL_PYR_TD + d0;
+            const uint32_t* q1 = s_tile + (sy1[rr] - rfirst) * PSL_PYR_TD + d0;
+            const uint32_t u0 = q0[0], u1 = q0[1], u2 = q0[2], v0 = q1[0], v1 = q1[1], v2 = q1[2];
+            const uint32_t bx = (uint32_t)(int)b[rr].x, by = (uint32_t)(int)b[rr].y;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool hi = ofs[j] >= 4;
+                const uint32_t t0 = __builtin_amdgcn_alignbyte(hi ? u2 : u1, hi ? u1 : u0, (uint32_t)(ofs[j] & 3));
+                const uint32_t t1 = __builtin_amdgcn_alignbyte(hi ? v2 : v1, hi ? v1 : v0, (uint32_t)(ofs[j] & 3));
+                const pyr_u16x2 cf = __builtin_bit_cast(pyr_u16x2, a[j]);
+                const uint32_t h0 = __builtin_amdgcn_udot2(__builtin_bit_cast(pyr_u16x2, __builtin_amdgcn_perm(0u, t0, 0x0c010c00u)), cf, 0u, false);
+                const uint32_t h1 = __builtin_amdgcn_udot2(__builtin_bit_cast(pyr_u16x2, __builtin_amdgcn_perm(0u, t1, 0x0c010c00u)), cf, 0u, false);
+                const uint32_t v = (((bx * (h0 >> 4)) >> 16) + ((by * (h1 >> 4)) >> 16) + 2u) >> 2;
+                packed |= (v & 0xffu) << (8 * j);
+            }
+        } else if (staged) {
             const uint8_t* t0 = reinterpret_cast<const uint8_t*>(s_tile) + (sy0[rr] - rfirst) * (PSL_PYR_TD * 4) - cbase;
             const uint8_t* t1 = reinterpret_cast<const uint8_t*>(s_tile) + (sy1[rr] - rfirst) * (PSL_PYR_TD * 4) - cbase;
 #pragma unroll
