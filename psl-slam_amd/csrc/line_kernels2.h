@@ -105,19 +105,24 @@ __device__ void psl_merge_two_lines(const float* l1, const float* l2, float* out
 // is a dependent ~1 us access (85 % of the kernel's wave time was s_waitcnt).  For n <= PSL_MERGE_LDSN (always, at
 // 640x480) the per-line arrays it chases live in LDS: cluster code, sort order / position, length, the two BFS
 // frontiers, the sub-cluster marks.  Larger inputs use the HBM arrays (same code through flat pointers).
+// The kernel exists for two sizes of that LDS working set: 512 lines (15 KB: 8 workgroups per CU; what a 640x480 frame
+// usually has) and 1024 lines (30 KB: 5 per CU).  Both are launched; a workgroup whose frame belongs to the other one exits.
 #define PSL_MERGE_LDSN 1024
+#define PSL_MERGE_LDSN_SMALL 512
 __device__ __forceinline__ int psl_block_excl_scan256(int v, int* s_w, int* total);
+template <int LN>
 struct MergeLds {
-    int code[PSL_MERGE_LDSN], order[PSL_MERGE_LDSN], pos[PSL_MERGE_LDSN], tc[PSL_MERGE_LDSN], nx[PSL_MERGE_LDSN], loc[PSL_MERGE_LDSN];
-    float length[PSL_MERGE_LDSN];
-    uint32_t bits[PSL_MERGE_LDSN / 32];
-    uint8_t clustered[PSL_MERGE_LDSN];
+    int code[LN], order[LN], pos[LN], tc[LN], nx[LN], loc[LN];
+    float length[LN];
+    uint32_t bits[LN / 32];
+    uint8_t clustered[LN];
     __attribute__((aligned(16))) uint32_t row[PSL_MERGE_NMAX / 32];  // the adjacency row being scanned by the serial clustering
 };
 
 // One adjacency row HBM -> LDS with the 16-byte loads of up to 8 quads in flight: the serial scan below would otherwise
 // pay one dependent round trip per 32-pair word.
-__device__ __forceinline__ const uint32_t* psl_merge_row(MergeLds& LD, const uint32_t* row, int words) {
+template <int LN>
+__device__ __forceinline__ const uint32_t* psl_merge_row(MergeLds<LN>& LD, const uint32_t* row, int words) {
     const uint4* r4 = reinterpret_cast<const uint4*>(row);
     uint4* d4 = reinterpret_cast<uint4*>(LD.row);
     const int nq = (words + 3) >> 2;
@@ -132,11 +137,12 @@ __device__ __forceinline__ const uint32_t* psl_merge_row(MergeLds& LD, const uin
     return LD.row;
 }
 
-__device__ int psl_merge_pass(const MergeScratch& M, MergeLds& LD, const float* src, float* dst, int n, float angle_threshold,
+template <int LN>
+__device__ int psl_merge_pass(const MergeScratch& M, MergeLds<LN>& LD, const float* src, float* dst, int n, float angle_threshold,
                               float distance_threshold, float endpoint_threshold, float length_thr, int* s_i) {
     const int tid = threadIdx.x, BS = 256;
     if (n <= 0) return 0;
-    const bool small = n <= PSL_MERGE_LDSN;
+    const bool small = n <= LN;
     const int words = (n + 31) >> 5;
     const int ROW = PSL_MERGE_NMAX / 32;
     for (int i = tid; i < n; i += BS) {
@@ -476,12 +482,14 @@ __device__ int psl_line_iterator_count(int w, int h, float fx1, float fy1, float
 // optimizeAndMergeLines_lsd + top-N + line equations: one workgroup per frame.
 // status bits: 1 = more than NMAX raw segments (truncated), 2 = cluster list overflow, 4 = more
 // than maxkl merged lines (truncated).
-__global__ __launch_bounds__(256) void k_line_merge(LineParams P, MergeScratch M0, const float* __restrict__ seg, const int* __restrict__ nseg,
+template <int LN>
+__global__ __launch_bounds__(256, LN <= PSL_MERGE_LDSN_SMALL ? 8 : 5) void k_line_merge(LineParams P, MergeScratch M0, const float* __restrict__ seg, const int* __restrict__ nseg,
                                                      PslKeyLine* __restrict__ kls, double* __restrict__ lineEq, int* __restrict__ nkl,
                                                      int* __restrict__ status) {
     __shared__ int s_i[4];
-    __shared__ MergeLds LD;
+    __shared__ MergeLds<LN> LD;
     const int frame = blockIdx.x, tid = threadIdx.x;
+    if ((nseg[frame] <= PSL_MERGE_LDSN_SMALL) != (LN == PSL_MERGE_LDSN_SMALL)) return;  // the other instance's frame
     const size_t f = (size_t)frame;
     MergeScratch M;
     M.lines0 = M0.lines0 + f * PSL_MERGE_NMAX * 4; M.lines1 = M0.lines1 + f * PSL_MERGE_NMAX * 4;

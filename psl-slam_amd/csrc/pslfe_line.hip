@@ -207,7 +207,8 @@ struct pslfe_line {
     int run_merge(int nframes) {
         PSL_HIP(hipSetDevice(ctx->device));
         PSL_STAGE_BEGIN(ctx, "line.merge");
-        k_line_merge<<<nframes, 256, 0, ctx->stream>>>(P, M, d_seg, d_nseg, d_kls, d_lineEq, d_nkl, d_status);
+        k_line_merge<PSL_MERGE_LDSN_SMALL><<<nframes, 256, 0, ctx->stream>>>(P, M, d_seg, d_nseg, d_kls, d_lineEq, d_nkl, d_status);
+        k_line_merge<PSL_MERGE_LDSN><<<nframes, 256, 0, ctx->stream>>>(P, M, d_seg, d_nseg, d_kls, d_lineEq, d_nkl, d_status);
         PSL_STAGE_END(ctx, "line.merge");
         PSL_HIP(hipGetLastError());
         return PSLFE_OK;

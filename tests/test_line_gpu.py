@@ -280,3 +280,21 @@ def test_line_extractor_xcd_grid_ragged_batch():
         k1, d1, e1 = single(frames[f])
         assert st == 0 and k.tobytes() == k1.tobytes() and (dsc == d1).all() and eq.tobytes() == e1.tobytes(), f"frame {f}"
     le.ctx.device_free(d_ptr)
+
+
+@pytest.mark.parametrize("nscenes", [2, 4])
+def test_merge_stage_more_segments_than_the_small_lds_instance(nscenes):
+    """k_line_merge exists for 512 and 1024 lines in LDS, beyond that its working set is in HBM: segment lists of ~700 and
+    ~1400 lines (several scenes' segments in one list) exercise the other two paths; same contract as above."""
+    import psl_slam_amd as P
+    import oracle_lib
+    seg = np.concatenate([oracle_lib.lsd_detect(_scene(st, sd)) for st, sd in (("desk", 4), ("struct", 3), ("desk", 9), ("desk", 12))[:nscenes]])
+    assert len(seg) > (512 if nscenes == 2 else 1024)
+    ref = oracle_lib.optimize_and_merge(seg, 640, 480, cap=4096)
+    got = P.LINEextractor().optimize_and_merge(seg, 640, 480, cap=4096)
+    assert len(got) == len(ref) and len(ref) > 100
+    ge = np.stack([got[n] for n in ("startPointX", "startPointY", "endPointX", "endPointY")], 1)
+    re_ = np.stack([ref[n] for n in ("startPointX", "startPointY", "endPointX", "endPointY")], 1)
+    assert np.abs(ge - re_).max() <= 0.01
+    np.testing.assert_array_equal(got["numOfPixels"], ref["numOfPixels"])
+    print(f"merge of {len(seg)} segments -> {len(got)} keylines, bit-identical {got.tobytes() == ref.tobytes()}")
