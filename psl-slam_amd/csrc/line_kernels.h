@@ -905,7 +905,8 @@ __device__ void lsdw_region2rect(const LsdW& F, int reg_size, double reg_angle, 
                                            : (double)psl_fast_atan2((float)Ixy, (float)PSL_DSUB(lambda, Iyy));
     theta = PSL_DMUL(theta, PSL_DEG2RAD);
     if (fabs(psl_angle_diff_signed(theta, reg_angle)) > prec) theta = PSL_DADD(theta, PSL_PI);
-    const double dx = cos(theta), dy = sin(theta);
+    double dx, dy;  // cos / sin of theta in [0, 3 pi): restricted-range evaluation (the general f64 pair costs ~250 instructions per
+    psl_cos_sin_f64(theta, &dx, &dy);  // rectangle on this serial path); the end points are rounded to f32 afterwards
     double l_min = 0, l_max = 0, w_min = 0, w_max = 0;  // order-independent: max(0, max l), min(0, min l)
     for (int j = F.lane; j < reg_size; j += 64) {
         const uint32_t rp = lsdw_reg(F, j, reg_size);

@@ -13,6 +13,30 @@
 #define PSL_SC64_QUAL static inline
 #endif
 
+// cos / sin of x in [0, ~4 pi] to about 1 ulp of f64 (n <= 8: n * pio2_1 is exact)
+PSL_SC64_QUAL void psl_cos_sin_f64(double x, double* c, double* s) {
+    const double n = __builtin_rint(x * 6.36619772367581382433e-01);
+    double r = __builtin_fma(-n, 1.57079632673412561417e+00, x);
+    r = __builtin_fma(-n, 6.07710050650619224932e-11, r);
+    const double z = r * r;
+    double ps = __builtin_fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+    ps = __builtin_fma(z, ps, 2.75573137070700676789e-06);
+    ps = __builtin_fma(z, ps, -1.98412698298579493134e-04);
+    ps = __builtin_fma(z, ps, 8.33333333332248946124e-03);
+    ps = __builtin_fma(z, ps, -1.66666666666666324348e-01);
+    const double sr = __builtin_fma(z * r, ps, r);
+    double pc = __builtin_fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+    pc = __builtin_fma(z, pc, -2.75573143513906633035e-07);
+    pc = __builtin_fma(z, pc, 2.48015872894767294178e-05);
+    pc = __builtin_fma(z, pc, -1.38888888888741095749e-03);
+    pc = __builtin_fma(z, pc, 4.16666666666666019037e-02);
+    const double cr = __builtin_fma(z * z, pc, __builtin_fma(-0.5, z, 1.0));
+    const int q = (int)n & 3;
+    const double cq = (q & 1) ? sr : cr, sq = (q & 1) ? cr : sr;
+    *c = (q == 1 || q == 2) ? -cq : cq;
+    *s = (q >= 2) ? -sq : sq;
+}
+
 PSL_SC64_QUAL void psl_cos_sin_2pi_f32(double x, float* c, float* s) {
     const double n = __builtin_rint(x * 6.36619772367581382433e-01);                 // x * 2/pi
     double r = __builtin_fma(-n, 1.57079632673412561417e+00, x);                     // pio2_1: first 33 bits of pi/2
