@@ -298,3 +298,22 @@ def test_merge_stage_more_segments_than_the_small_lds_instance(nscenes):
     assert np.abs(ge - re_).max() <= 0.01
     np.testing.assert_array_equal(got["numOfPixels"], ref["numOfPixels"])
     print(f"merge of {len(seg)} segments -> {len(got)} keylines, bit-identical {got.tobytes() == ref.tobytes()}")
+
+
+def test_lsd_segments_bit_identical_over_many_frames():
+    """The region growing decides most neighbours against an angle that is NOT up to date (a rigorous bound on its drift
+    replaces the per-pixel fastAtan2, line_kernels.h): every shortcut must give the reference's decision, so the segment
+    lists of many different frames are compared bit for bit (textured and structure-like scenes, several time steps)."""
+    import psl_slam_amd as P
+    import oracle_lib
+    le = P.LINEextractor()
+    nseg = 0
+    for style, seed in (("desk", 31), ("struct", 32), ("desk", 33), ("struct", 34)):
+        sc = sf.Scene(640, 480, style, seed)
+        for t in range(0, 12, 2):
+            img = sc.gray(t)
+            got = le.lsd_detect(img)
+            ref = oracle_lib.lsd_detect(img)
+            assert got.shape == ref.shape and (got.view(np.uint32) == ref.view(np.uint32)).all(), (style, seed, t)
+            nseg += len(ref)
+    assert nseg > 5000
