@@ -2,8 +2,9 @@
 // structural-line (LIL/LJL) pairing.  Product code.  See line_kernels.h for the reference map.
 // Convention shared with the oracle: unqualified libm calls on float arguments in the reference
 // (atan, atan2, tan, sin, cos) are the float overloads; sinf/cosf are psl_sincosf (bit-identical to
-// glibc on [-2pi, 2pi]), atanf/atan2f/tanf and the double atan/sin/cos of MergeTwoLines come from the
-// device math library (last-ulp differences vs glibc are possible there; tolerance in the tests).
+// glibc on [-2pi, 2pi]), atanf / atan2f are psl_atanf / psl_atan2f (glibc's float algorithms restated, pinned against libm);
+// tanf and the double sin/cos of MergeTwoLines come from the device math library (last-ulp differences vs glibc are possible
+// there; tolerance in the tests).
 #ifndef PSL_LINE_KERNELS2_H
 #define PSL_LINE_KERNELS2_H
 
@@ -80,8 +81,8 @@ __device__ void psl_merge_two_lines(const float* l1, const float* l2, float* out
     const double den = PSL_DMUL(2.0, PSL_DADD(li, lj));
     const double xg = PSL_DADD(PSL_DMUL(li, (double)PSL_FADD(ax, bx)), PSL_DMUL(lj, (double)PSL_FADD(cx, dx))) / den;
     const double yg = PSL_DADD(PSL_DMUL(li, (double)PSL_FADD(ay, by)), PSL_DMUL(lj, (double)PSL_FADD(cy, dy))) / den;
-    const double thi = dlix == 0.0f ? PSL_PI / 2.0 : (double)atanf(PSL_FDIV(dliy, dlix));
-    const double thj = dljx == 0.0f ? PSL_PI / 2.0 : (double)atanf(PSL_FDIV(dljy, dljx));
+    const double thi = dlix == 0.0f ? PSL_PI / 2.0 : (double)psl_atanf(PSL_FDIV(dliy, dlix));
+    const double thj = dljx == 0.0f ? PSL_PI / 2.0 : (double)psl_atanf(PSL_FDIV(dljy, dljx));
     double thr;
     if (fabs(PSL_DSUB(thi, thj)) <= PSL_PI / 2.0) thr = PSL_DADD(PSL_DMUL(li, thi), PSL_DMUL(lj, thj)) / PSL_DADD(li, lj);
     else {
@@ -147,7 +148,7 @@ __device__ int psl_merge_pass(const MergeScratch& M, MergeLds<LN>& LD, const flo
     const int ROW = PSL_MERGE_NMAX / 32;
     for (int i = tid; i < n; i += BS) {
         const float dx = PSL_FSUB(src[4 * i + 2], src[4 * i]), dy = PSL_FSUB(src[4 * i + 3], src[4 * i + 1]);
-        M.angles[i] = atanf(PSL_FDIV(dy, dx));  // Eigen ArrayXf::atan()
+        M.angles[i] = psl_atanf(PSL_FDIV(dy, dx));  // Eigen ArrayXf::atan()
         const float len = sqrtf(PSL_FADD(PSL_FMUL(dx, dx), PSL_FMUL(dy, dy)));
         M.length[i] = len;
         M.code[i] = -1;
@@ -521,7 +522,7 @@ __global__ __launch_bounds__(256, LN <= PSL_MERGE_LDSN_SMALL ? 8 : 5) void k_lin
         kl.sPointInOctaveX = l[0]; kl.sPointInOctaveY = l[1]; kl.ePointInOctaveX = l[2]; kl.ePointInOctaveY = l[3];
         const double ex = (double)PSL_FSUB(l[0], l[2]), ey = (double)PSL_FSUB(l[1], l[3]);
         kl.lineLength = (float)__dsqrt_rn(PSL_DADD(PSL_DMUL(ex, ex), PSL_DMUL(ey, ey)));
-        kl.angle = atan2f(PSL_FSUB(kl.endPointY, kl.startPointY), PSL_FSUB(kl.endPointX, kl.startPointX));
+        kl.angle = psl_atan2f(PSL_FSUB(kl.endPointY, kl.startPointY), PSL_FSUB(kl.endPointX, kl.startPointX));
         kl.class_id = i;
         kl.octave = 0;
         kl.size = PSL_FMUL(PSL_FSUB(kl.endPointX, kl.startPointX), PSL_FSUB(kl.endPointY, kl.startPointY));

@@ -128,4 +128,6 @@ PSL_HD void psl_sincosf(float y, float* sinp, float* cosp) {
     *cosp = psl_sincos_poly(xs, x2, n ^ 1, n & 2);
 }
 
+#include "psl_atanf.h"  // psl_atanf, psl_atan2f
+
 #endif

@@ -96,9 +96,9 @@ def _kl_equal(a, b, what, skip=()):
 
 @pytest.mark.parametrize("style,seed", [("struct", 3), ("desk", 4), ("struct", 8)])
 def test_merge_stage_on_oracle_segments(style, seed):
-    """optimizeAndMergeLines_lsd on identical input segments.  The merge uses atanf / atan2f / double
-    sin, cos from the device math library vs glibc in the oracle (last-ulp differences possible), so
-    the contract is a tolerance: same number of lines, endpoints within 0.01 px; bit-identity is
+    """optimizeAndMergeLines_lsd on identical input segments.  atanf / atan2f are glibc's algorithms restated (pinned against
+    libm in the CPU suite); the double sin, cos of MergeTwoLines come from the device math library vs glibc in the oracle
+    (last-ulp differences possible), so the contract is a tolerance: same number of lines, endpoints within 0.01 px; bit-identity is
     reported."""
     import psl_slam_amd as P
     import oracle_lib

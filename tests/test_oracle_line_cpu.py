@@ -131,3 +131,16 @@ def test_fast_atan2_error_bound_used_by_the_lazy_region_angle():
         d = np.abs(f - t)
         worst = max(worst, float(np.minimum(d, 360.0 - d).max()))
     assert worst < 0.02, worst
+
+
+def test_restated_atanf_atan2f_equal_libm(tmp_path):
+    """The line merging calls atanf / atan2f; the device uses glibc's float algorithms restated (psl-slam_amd/csrc/psl_atanf.h).
+    oracle/atanf_check.c runs that header on the host against libm: atanf for every float, atan2f on 2e8 pairs."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "atanf_check")
+    subprocess.run(["gcc", "-O2", "-ffp-contract=off", "-o", exe, os.path.join(root, "oracle", "atanf_check.c"), "-lm", "-lpthread"], check=True)
+    for mode in ("0", "1"):
+        out = subprocess.run([exe, mode], capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0 and "mismatches 0" in out.stdout, out.stdout
