@@ -245,7 +245,8 @@ def main():
         import synth_frames as sf
         dsc = sf.Scene(W, H, "struct", P_seed(rank))
         depth_h = np.stack([dsc.depth_u16(t).astype(np.float32) / np.float32(5000.0) for t in range(16)], 0)
-        depth_d = torch.from_numpy(np.ascontiguousarray(np.concatenate([depth_h] * ((B + 15) // 16), 0)[:B])).to(dev)
+        # tiled on the device: the host never holds more than the 16 distinct depth frames (8 ranks share one node's memory)
+        depth_d = torch.from_numpy(depth_h).to(dev).repeat((B + 15) // 16, 1, 1)[:B].contiguous()
         glue = P.FrameGlue(max_lines=klcap, max_fans=4096, max_batch=B, ctx=ctx_l)
         cam = np.zeros((), P.CAMERA_DTYPE)
         for k_, v_ in zip(P.CAMERA_DTYPE.names, (517.306408, 516.469215, 318.643040, 255.313989, 0, 0, 0, 0, 0, 40.0)):
