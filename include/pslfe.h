@@ -164,6 +164,14 @@ typedef struct pslfe_line pslfe_line;  /* == LINEextractor object               
 int pslfe_line_create(pslfe_ctx* ctx, int numOctaves, float scale, int nLSDFeature, double min_line_length,
                       int max_batch, pslfe_line** out);
 void pslfe_line_destroy(pslfe_line* line);
+/* Refinement mode of the LSD behind the extractor (cv::createLineSegmentDetector(refine), OpenCV 3.x lsd.cpp).  The
+ * reference calls the STOCK contrib cv::line_descriptor::LSDDetector (add_src/LineExtractor.cpp:336-337, linked by
+ * CMakeLists.txt:96), whose source is not in its tree: upstream constructs the detector with LSD_REFINE_ADV
+ * (rect_improve + NFA test, log_eps 0), which is the default here; the vendored, never-called LSDDetectorC
+ * (Thirdparty/line_descriptor/src/LSDDetector_custom.cpp:185) uses LSD_REFINE_STD (no NFA test). */
+#define PSLFE_LSD_REFINE_STD 1
+#define PSLFE_LSD_REFINE_ADV 2
+int pslfe_line_set_refine(pslfe_line* line, int refine);
 /* == GetLevels / GetScaleFactor / GetScaleFactors ... add_inc/LineExtractor.h:211-233 */
 int pslfe_line_levels(const pslfe_line* line);
 float pslfe_line_scale_factor(const pslfe_line* line);

@@ -9,8 +9,16 @@
 //                                         60,76-118,219-261,351-413,540-688,1027-1373
 //   CPartiallyRecoverConnectivity         add_src/PartiallyRecoverConnectivity.cpp:14-247
 // PARITY UNPINNED (no fixtures upstream, OpenCV absent).  Conventions chosen where the reference
-// leaves behaviour open: OpenCV-3.x LSD with default LSD_REFINE_STD (no NFA step);
-// its seed loop walks the coordinate list by index, i.e. in raster order (the bin-sorted links it
+// leaves behaviour open: OpenCV-3.x LSD.  The reference calls the STOCK contrib class
+// cv::line_descriptor::LSDDetector (add_src/LineExtractor.cpp:336, linked with -lopencv_line_descriptor,
+// CMakeLists.txt:96), whose source is not in the tree; upstream opencv_contrib's detectImpl constructs
+// createLineSegmentDetector(LSD_REFINE_ADV), so the default here is LSD_REFINE_ADV: rect_improve + the
+// NFA test at log_eps = 0 (restated from the published lsd.cpp; the nfa() / log_gamma() arithmetic has a
+// twin in the tree, Thirdparty/line_descriptor/src/ED_Lib/NFA.cpp:106-240).  The vendored, never-called
+// LSDDetectorC (Thirdparty/line_descriptor/src/LSDDetector_custom.cpp:185) uses the default
+// LSD_REFINE_STD; pso_set_lsd_refine(1) selects that.  Which of the two the linked library used cannot
+// be verified offline.  The
+// seed loop walks the coordinate list by index, i.e. in raster order (the bin-sorted links it
 // builds are never followed); std::sort calls whose ties reach the output are stable with index
 // tie-break (H16); no FMA contraction (H6); empty input -> empty output (H12); unqualified libm
 // calls on float arguments (cos, sin, tan, atan, atan2) resolve to the float overloads, as they do
@@ -24,6 +32,9 @@
 
 #include "psl_math_oracle.h"
 #include "psl_oracle.h"
+
+#define PSL_F64_QUAL static inline
+#include "../psl-slam_amd/csrc/psl_f64math.h"  // optional: the product's restated log / exp / log10 (pso_set_nfa_math(1))
 
 namespace {
 
@@ -39,7 +50,10 @@ inline int reflect101(int p, int n) {
     return p;
 }
 
-// ================================ LSD (OpenCV 3.x, LSD_REFINE_STD) ================================
+int g_lsd_refine = 2;   // 1 = LSD_REFINE_STD, 2 = LSD_REFINE_ADV (default, see the header)
+int g_nfa_math = 0;     // 0 = this host's libm (what the reference calls), 1 = psl_f64math.h (what the device evaluates)
+
+// ================================ LSD (OpenCV 3.x) ================================
 struct RegionPoint { int x, y; double angle, modgrad; };
 struct Rect { double x1, y1, x2, y2, width, x, y, theta, dx, dy, prec, p; };
 
@@ -257,12 +271,183 @@ struct Lsd {
         return true;
     }
 
+    // ---- LSD_REFINE_ADV: rect_nfa / nfa / rect_improve (OpenCV 3.x lsd.cpp; nfa() and log_gamma() as in
+    //      Thirdparty/line_descriptor/src/ED_Lib/NFA.cpp:106-240) ----
+    double LOG_NT = 0;
+    std::vector<double>* debug_rects = nullptr;  // tap: the rectangles handed to rect_improve (12 doubles each, Rect layout)
+    static double m_log(double x) { return g_nfa_math ? psl_log(x) : std::log(x); }
+    static double m_exp(double x) { return g_nfa_math ? psl_exp(x) : std::exp(x); }
+    static double m_log10(double x) { return g_nfa_math ? psl_log10(x) : std::log10(x); }
+    // pow(x, n) for the integer-valued arguments log_gamma sees: exact products where libm's pow is exact too
+    // (x <= 15, n <= 6), x^6 = (x^3)^2 with x^3 exact (one rounding, as a < 1 ulp pow returns) for the Windschitl term
+    static double m_pow(double x, double y) {
+        if (!g_nfa_math) return std::pow(x, y);
+        if (y == (double)(int)y && y >= 0 && y <= 6 && x == std::floor(x)) {
+            if (y == 6) { const double c = x * x * x; return c * c; }
+            double r = 1; for (int i = 0; i < (int)y; ++i) r *= x; return r;
+        }
+        return psl_pow_pos(x, y);
+    }
+    static double m_sinh(double x) { return g_nfa_math ? psl_sinh_small(x) : std::sinh(x); }
+    static double log_gamma_windschitl(double x) {
+        return 0.918938533204673 + (x - 0.5) * m_log(x) - x + 0.5 * x * m_log(x * m_sinh(1 / x) + 1 / (810.0 * m_pow(x, 6.0)));
+    }
+    static double log_gamma_lanczos(double x) {
+        static const double q[7] = {75122.6331530, 80916.6278952, 36308.2951477, 8687.24529705, 1168.92649479, 83.8676043424, 2.50662827511};
+        double a = (x + 0.5) * m_log(x + 5.5) - (x + 5.5);
+        double b = 0;
+        for (int n = 0; n < 7; ++n) {
+            a -= m_log(x + double(n));
+            b += q[n] * m_pow(x, double(n));
+        }
+        return a + m_log(b);
+    }
+    static double log_gamma(double x) { return x > 15.0 ? log_gamma_windschitl(x) : log_gamma_lanczos(x); }
+    static bool double_equal(double a, double b) {
+        if (a == b) return true;
+        const double abs_diff = std::fabs(a - b), aa = std::fabs(a), bb = std::fabs(b);
+        double abs_max = aa > bb ? aa : bb;
+        if (abs_max < 2.2250738585072014e-308) abs_max = 2.2250738585072014e-308;  // DBL_MIN
+        return (abs_diff / abs_max) <= (100.0 * 2.2204460492503131e-16);            // RELATIVE_ERROR_FACTOR * DBL_EPSILON
+    }
+    double nfa(int n, int k, double p) const {
+        if (n == 0 || k == 0) return -LOG_NT;
+        if (n == k) return -LOG_NT - double(n) * m_log10(p);
+        const double p_term = p / (1 - p);
+        const double log1term = log_gamma(double(n) + 1) - log_gamma(double(k) + 1) - log_gamma(double(n - k) + 1)
+                                + double(k) * m_log(p) + double(n - k) * m_log(1.0 - p);
+        double term = m_exp(log1term);
+        if (double_equal(term, 0)) {
+            if (k > n * p) return -log1term / 2.30258509299404568402 - LOG_NT;  // M_LN10
+            return -LOG_NT;
+        }
+        double bin_tail = term;
+        const double tolerance = 0.1;
+        for (int i = k + 1; i <= n; ++i) {
+            const double bin_term = double(n - i + 1) / double(i);
+            const double mult_term = bin_term * p_term;
+            term *= mult_term;
+            bin_tail += term;
+            if (bin_term < 1) {
+                const double err = term * ((1 - m_pow(mult_term, double(n - i + 1))) / (1 - mult_term) - 1);
+                if (err < tolerance * std::fabs(-m_log10(bin_tail) - LOG_NT) * bin_tail) break;
+            }
+        }
+        return -m_log10(bin_tail) - LOG_NT;
+    }
+    // The rectangle scan of OpenCV 3.x as it behaves: corners truncated to int, slopes by INTEGER division, the second
+    // slopes take `tailp->p.x` where the y coordinate was meant, and a row outside the image is skipped WITHOUT
+    // advancing the column bounds.
+    struct Edge { int x, y; bool taken; };
+    void rect_counts(const Rect& rec, int* total, int* aligned) const {
+        int total_pts = 0, alg_pts = 0;
+        const double half_width = rec.width / 2.0;
+        const double dyhw = rec.dy * half_width, dxhw = rec.dx * half_width;
+        Edge e[4] = {{int(rec.x1 - dyhw), int(rec.y1 + dxhw), false}, {int(rec.x2 - dyhw), int(rec.y2 + dxhw), false},
+                     {int(rec.x2 + dyhw), int(rec.y2 - dxhw), false}, {int(rec.x1 + dyhw), int(rec.y1 - dxhw), false}};
+        std::sort(e, e + 4, [](const Edge& a, const Edge& b) { return a.x == b.x ? a.y < b.y : a.x < b.x; });
+        Edge *min_y = &e[0], *max_y = &e[0];
+        for (int i = 1; i < 4; ++i) {
+            if (min_y->y > e[i].y) min_y = &e[i];
+            if (max_y->y < e[i].y) max_y = &e[i];
+        }
+        min_y->taken = true;
+        Edge* leftmost = nullptr;
+        for (int i = 0; i < 4; ++i) if (!e[i].taken) { if (!leftmost) leftmost = &e[i]; else if (leftmost->x > e[i].x) leftmost = &e[i]; }
+        leftmost->taken = true;
+        Edge* rightmost = nullptr;
+        for (int i = 0; i < 4; ++i) if (!e[i].taken) { if (!rightmost) rightmost = &e[i]; else if (rightmost->x < e[i].x) rightmost = &e[i]; }
+        rightmost->taken = true;
+        Edge* tailp = nullptr;
+        for (int i = 0; i < 4; ++i) if (!e[i].taken) { if (!tailp) tailp = &e[i]; else if (tailp->x > e[i].x) tailp = &e[i]; }
+        tailp->taken = true;
+        const double flstep = (min_y->y != leftmost->y) ? (min_y->x - leftmost->x) / (min_y->y - leftmost->y) : 0;
+        const double slstep = (leftmost->y != tailp->x) ? (leftmost->x - tailp->x) / (leftmost->y - tailp->x) : 0;
+        const double frstep = (min_y->y != rightmost->y) ? (min_y->x - rightmost->x) / (min_y->y - rightmost->y) : 0;
+        const double srstep = (rightmost->y != tailp->x) ? (rightmost->x - tailp->x) / (rightmost->y - tailp->x) : 0;
+        double lstep = flstep, rstep = frstep;
+        double left_x = min_y->x, right_x = min_y->x;
+        const int min_iter = min_y->y, max_iter = max_y->y;
+        for (int y = min_iter; y <= max_iter; ++y) {
+            if (y < 0 || y >= H) continue;
+            for (int x = int(left_x); x <= int(right_x); ++x) {
+                if (x < 0 || x >= W) continue;
+                ++total_pts;
+                if (is_aligned(x + y * W, rec.theta, rec.prec)) ++alg_pts;
+            }
+            if (y >= leftmost->y) lstep = slstep;
+            if (y >= rightmost->y) rstep = srstep;
+            left_x += lstep;
+            right_x += rstep;
+        }
+        *total = total_pts; *aligned = alg_pts;
+    }
+    double rect_nfa(const Rect& rec) const {
+        int n, k;
+        rect_counts(rec, &n, &k);
+        return nfa(n, k, rec.p);
+    }
+    double rect_improve(Rect& rec) const {
+        const double delta = 0.5, delta_2 = delta / 2.0, LOG_EPS = 0;
+        double log_nfa = rect_nfa(rec);
+        if (log_nfa > LOG_EPS) return log_nfa;
+        Rect r = rec;
+        for (int n = 0; n < 5; ++n) {  // finer precision
+            r.p /= 2;
+            r.prec = r.p * kPI;
+            const double v = rect_nfa(r);
+            if (v > log_nfa) { log_nfa = v; rec = r; }
+        }
+        if (log_nfa > LOG_EPS) return log_nfa;
+        r = rec;
+        for (int n = 0; n < 5; ++n) {  // reduce width
+            if ((r.width - delta) >= 0.5) {
+                r.width -= delta;
+                const double v = rect_nfa(r);
+                if (v > log_nfa) { rec = r; log_nfa = v; }
+            }
+        }
+        if (log_nfa > LOG_EPS) return log_nfa;
+        r = rec;
+        for (int n = 0; n < 5; ++n) {  // reduce one side
+            if ((r.width - delta) >= 0.5) {
+                r.x1 += -r.dy * delta_2; r.y1 += r.dx * delta_2;
+                r.x2 += -r.dy * delta_2; r.y2 += r.dx * delta_2;
+                r.width -= delta;
+                const double v = rect_nfa(r);
+                if (v > log_nfa) { rec = r; log_nfa = v; }
+            }
+        }
+        if (log_nfa > LOG_EPS) return log_nfa;
+        r = rec;
+        for (int n = 0; n < 5; ++n) {  // reduce the other side
+            if ((r.width - delta) >= 0.5) {
+                r.x1 -= -r.dy * delta_2; r.y1 -= r.dx * delta_2;
+                r.x2 -= -r.dy * delta_2; r.y2 -= r.dx * delta_2;
+                r.width -= delta;
+                const double v = rect_nfa(r);
+                if (v > log_nfa) { rec = r; log_nfa = v; }
+            }
+        }
+        if (log_nfa > LOG_EPS) return log_nfa;
+        r = rec;
+        for (int n = 0; n < 5; ++n) {  // finer precision again
+            if ((r.width - delta) >= 0.5) {
+                r.p /= 2;
+                r.prec = r.p * kPI;
+                const double v = rect_nfa(r);
+                if (v > log_nfa) { rec = r; log_nfa = v; }
+            }
+        }
+        return log_nfa;
+    }
+
     void detect(const uint8_t* gray, int w, int h, int stride, std::vector<float>& lines) {
         const double SCALE = 0.8, QUANT = 2.0, ANG_TH = 22.5, DENSITY_TH = 0.7;
         const double prec = kPI * ANG_TH / 180, p = ANG_TH / 180, rho = QUANT / std::sin(prec);
         scale_image(gray, w, h, stride);
         ll_angle(rho);
-        const double LOG_NT = 5 * (std::log10(double(W)) + std::log10(double(H))) / 2 + std::log10(11.0);
+        LOG_NT = 5 * (std::log10(double(W)) + std::log10(double(H))) / 2 + std::log10(11.0);
         const size_t min_reg_size = size_t(-LOG_NT / std::log10(p));
         used.assign((size_t)W * H, 0);
         std::vector<RegionPoint> reg((size_t)W * H);
@@ -278,6 +463,11 @@ struct Lsd {
                 Rect rec;
                 region2rect(reg, reg_size, reg_angle, prec, p, rec);
                 if (!refine(reg, reg_size, reg_angle, prec, p, rec, DENSITY_TH)) continue;
+                if (g_lsd_refine >= 2) {  // LSD_REFINE_ADV
+                    if (debug_rects) { const double* f = &rec.x1; debug_rects->insert(debug_rects->end(), f, f + 12); }
+                    const double log_nfa = rect_improve(rec);
+                    if (log_nfa <= 0) continue;  // LOG_EPS = 0
+                }
                 rec.x1 += 0.5; rec.y1 += 0.5; rec.x2 += 0.5; rec.y2 += 0.5;
                 rec.x1 /= SCALE; rec.y1 /= SCALE; rec.x2 /= SCALE; rec.y2 /= SCALE;
                 lines.push_back(float(rec.x1)); lines.push_back(float(rec.y1));
@@ -653,6 +843,31 @@ double det2(float a, float b, float c, float d) { return (double)a * d - (double
 }  // namespace
 
 extern "C" {
+
+// 1 = LSD_REFINE_STD, 2 = LSD_REFINE_ADV (default); returns the previous mode
+int pso_set_lsd_refine(int mode) { const int old = g_lsd_refine; if (mode == 1 || mode == 2) g_lsd_refine = mode; return old; }
+// 0 = host libm in nfa() (default, what the reference calls), 1 = the product's restated functions; returns the previous mode
+int pso_set_nfa_math(int restated) { const int old = g_nfa_math; g_nfa_math = restated ? 1 : 0; return old; }
+// nfa(n, k, p) for an image of W x H (scaled) pixels, and the rectangle counts of rect_nfa: taps for the unit tests
+double pso_lsd_nfa(int n, int k, double p, int W, int H) {
+    Lsd l;
+    l.LOG_NT = 5 * (std::log10(double(W)) + std::log10(double(H))) / 2 + std::log10(11.0);
+    return l.nfa(n, k, p);
+}
+// rectangles that reach rect_improve (12 doubles each: x1 y1 x2 y2 width x y theta dx dy prec p); returns their number
+int pso_lsd_rects(const uint8_t* gray, int w, int h, int stride, double* rects, int cap) {
+    Lsd lsd;
+    std::vector<double> r;
+    std::vector<float> v;
+    lsd.debug_rects = &r;
+    const int keep = g_lsd_refine;
+    g_lsd_refine = 2;
+    lsd.detect(gray, w, h, stride, v);
+    g_lsd_refine = keep;
+    const int n = (int)r.size() / 12;
+    for (int i = 0; i < n && i < cap; ++i) memcpy(rects + 12 * i, &r[12 * (size_t)i], 96);
+    return n;
+}
 
 // LSD + contrib wrapper clamp: returns number of segments, lines = x1,y1,x2,y2 floats
 int pso_lsd_detect(const uint8_t* gray, int w, int h, int stride, float* lines, int cap) {

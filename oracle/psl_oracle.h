@@ -100,6 +100,10 @@ void pso_line_fuse_best(const PsoKeyLine* kls, int n, const uint8_t* desc, int n
 void pso_distinctive_descriptors(const uint8_t* desc, const int32_t* offsets, int npts, int* best);
 int pso_line_match_nnr(const uint8_t* d1, int n1, const uint8_t* d2, int n2, float nnr, int* matches12);
 
+int pso_set_lsd_refine(int mode);   /* 1 = LSD_REFINE_STD, 2 = LSD_REFINE_ADV (default) */
+int pso_set_nfa_math(int restated); /* 0 = host libm (default), 1 = psl_f64math.h */
+double pso_lsd_nfa(int n, int k, double p, int W, int H);
+int pso_lsd_rects(const uint8_t* gray, int w, int h, int stride, double* rects, int cap);
 int pso_lsd_detect(const uint8_t* gray, int w, int h, int stride, float* lines, int cap);
 int pso_lsd_gradient(const uint8_t* gray, int w, int h, int stride, double* scaled, double* angles, double* modgrad, int* W, int* H);
 int pso_merge_lines(const float* src, int n, float ang, float dist, float ep, float* dst, int cap);

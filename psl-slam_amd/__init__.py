@@ -496,6 +496,13 @@ class LINEextractor:
                                        C.c_double(min_line_length), C.c_int(max_batch), C.byref(self._h)), "pslfe_line_create")
         lib().pslfe_line_scale_factor.restype = C.c_float
 
+    LSD_REFINE_STD, LSD_REFINE_ADV = 1, 2
+
+    def set_refine(self, mode):
+        """cv::createLineSegmentDetector(refine) behind the extractor: LSD_REFINE_ADV (default: rect_improve + NFA test, what
+        the stock contrib LSDDetector constructs) or LSD_REFINE_STD (the vendored, never-called LSDDetectorC)."""
+        _check(lib().pslfe_line_set_refine(self._h, C.c_int(mode)), "pslfe_line_set_refine")
+
     def GetLevels(self):
         return lib().pslfe_line_levels(self._h)
 

@@ -1,8 +1,10 @@
 // HIP kernels of the line front-end (gfx950, wave64). Product code.
 // Reference behaviour reproduced:
-//   cv::createLineSegmentDetector() defaults (OpenCV 3.x lsd.cpp, LSD_REFINE_STD; not in the
-//   reference tree, restated from the published algorithm — SURVEY Appendix A.9) behind the contrib
-//   wrapper Thirdparty/line_descriptor/src/LSDDetector_custom.cpp:166-251
+//   cv::createLineSegmentDetector(LSD_REFINE_ADV | LSD_REFINE_STD) (OpenCV 3.x lsd.cpp; not in the
+//   reference tree, restated from the published algorithm — SURVEY Appendix A.9) behind the stock contrib
+//   wrapper cv::line_descriptor::LSDDetector the reference links (add_src/LineExtractor.cpp:336-337; its
+//   vendored twin: Thirdparty/line_descriptor/src/LSDDetector_custom.cpp:166-251).  ADV (rect_improve + NFA,
+//   line_kernels3.h) is the default, STD is selected with pslfe_line_set_refine
 //   optimizeAndMergeLines_lsd            add_src/uselongline.cpp:24-485
 //   BinaryDescriptor::compute (LBD)      Thirdparty/line_descriptor/src/binary_descriptor_custom.cpp:351-413, 1027-1373
 //   CPartiallyRecoverConnectivity        add_src/PartiallyRecoverConnectivity.cpp:14-247
@@ -20,6 +22,8 @@
 #define PSL_LSD_NOTDEF (-1024.0f)   // angle map label for "gradient undefined" (stored as f32 degrees)
 #define PSL_SC64_QUAL __host__ __device__ static inline
 #include "psl_sincos64.h"
+#define PSL_F64_QUAL __host__ __device__ static inline
+#include "psl_f64math.h"
 #define PSL_PI 3.1415926535897932384626433832795
 #define PSL_DEG2RAD (PSL_PI / 180)
 
@@ -33,6 +37,8 @@ struct LineParams {
     double rho, prec, p;      // gradient threshold, angle tolerance (rad), p = ANG_TH/180
     double rho_q;             // largest q with sqrt(q) <= rho: `norm <= rho` decided on the squared magnitude
     int min_reg_size;
+    int refine;               // 1 = LSD_REFINE_STD (segments leave k_lsd_grow3), 2 = LSD_REFINE_ADV (rectangles -> k_lsd_nfa -> k_lsd_emit)
+    double log_nt;            // LOG_NT of the NFA: 5 (log10 W + log10 H) / 2 + log10 11
     int full_grad;            // k_lsd_grad stores the gradient magnitude of every pixel (debug tap), not only where the angle is defined
     int lbdK[5];              // integer Gaussian 5x5 sigma 1 (OpenCV 3.2 8-bit path)
     float gaussG[63], gaussL[21];
@@ -59,60 +65,13 @@ __device__ __forceinline__ int psl_reflect101i(int p, int n) {
 
 // ---------------------------------------------------------------------------------------------
 // LSD step 1: GaussianBlur(CV_64F, 7x7, sigma 0.75, REFLECT_101) + resize(0.8, INTER_LINEAR) on
-// doubles. One thread per scaled pixel recomputes the 2x2 blurred samples it needs (8 rows x 2
-// columns of row sums) in the summation order of OpenCV's RowFilter / SymmColumnFilter.
-// Scale 0.8 -> 1/scale = 1.25 and the bilinear weights {0.125,0.375,0.625,0.875} are exact, so
-// the tables are computed inline exactly as cv::resize computes them.
+// doubles, in the summation order of OpenCV's RowFilter / SymmColumnFilter.  Scale 0.8 -> 1/scale =
+// 1.25 and the bilinear weights {0.125,0.375,0.625,0.875} are exact, so the tables are computed
+// inline exactly as cv::resize computes them.  A 64 x 16 tile of the working image needs <= 82 x 22
+// blurred samples, i.e. <= 88 x 28 input pixels; they are staged once in LDS (reflect-101 applied
+// while loading), row sums and column sums are formed once per sample, and the bilinear step reads
+// the blurred tile.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ double psl_lsd_rowsum(const uint8_t* __restrict__ row, int x, int w, const double* gk) {
-    double s = PSL_DMUL(gk[0], (double)row[psl_reflect101i(x - 3, w)]);
-#pragma unroll
-    for (int j = 1; j < 7; ++j) s = PSL_DADD(s, PSL_DMUL(gk[j], (double)row[psl_reflect101i(x - 3 + j, w)]));
-    return s;
-}
-
-__device__ __forceinline__ double psl_lsd_blur_at(const uint8_t* __restrict__ img, int stride, int x, int y, int w, int h, const double* gk) {
-    double rs[7];
-#pragma unroll
-    for (int j = 0; j < 7; ++j) rs[j] = psl_lsd_rowsum(img + (size_t)psl_reflect101i(y - 3 + j, h) * stride, x, w, gk);
-    double s = PSL_DMUL(gk[3], rs[3]);
-#pragma unroll
-    for (int j = 1; j <= 3; ++j) s = PSL_DADD(s, PSL_DMUL(gk[3 + j], PSL_DADD(rs[3 + j], rs[3 - j])));
-    return s;
-}
-
-__global__ __launch_bounds__(256) void k_lsd_scale(LineParams P, const uint8_t* __restrict__ gray, int stride, size_t fstride,
-                                                    double* __restrict__ scaled) {
-    const int frame = blockIdx.z;
-    const int dx = blockIdx.x * 64 + (threadIdx.x & 63), dy = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (dx >= P.W || dy >= P.H) return;
-    const uint8_t* img = gray + (size_t)frame * fstride;
-    // cv::resize tables (float offsets, float coefficients; horizontal coefficient cleared at the clamps)
-    const double sc = 1. / 0.8;
-    float fx = (float)((dx + 0.5) * sc - 0.5), fy = (float)((dy + 0.5) * sc - 0.5);
-    int sx = (int)__builtin_floorf(fx), sy = (int)__builtin_floorf(fy);
-    fx -= sx; fy -= sy;
-    if (sx < 0) { fx = 0; sx = 0; }
-    if (sx >= P.w - 1) { fx = 0; sx = P.w - 1; }
-    const double a0 = (double)(1.f - fx), a1 = (double)fx, b0 = (double)(1.f - fy), b1 = (double)fy;
-    int sy0 = sy, sy1 = sy + 1;
-    sy0 = sy0 < 0 ? 0 : (sy0 >= P.h ? P.h - 1 : sy0);
-    sy1 = sy1 < 0 ? 0 : (sy1 >= P.h ? P.h - 1 : sy1);
-    double h0, h1;
-    if (sx + 1 < P.w) {
-        h0 = PSL_DADD(PSL_DMUL(psl_lsd_blur_at(img, stride, sx, sy0, P.w, P.h, P.gk), a0), PSL_DMUL(psl_lsd_blur_at(img, stride, sx + 1, sy0, P.w, P.h, P.gk), a1));
-        h1 = PSL_DADD(PSL_DMUL(psl_lsd_blur_at(img, stride, sx, sy1, P.w, P.h, P.gk), a0), PSL_DMUL(psl_lsd_blur_at(img, stride, sx + 1, sy1, P.w, P.h, P.gk), a1));
-    } else {
-        h0 = psl_lsd_blur_at(img, stride, sx, sy0, P.w, P.h, P.gk);
-        h1 = psl_lsd_blur_at(img, stride, sx, sy1, P.w, P.h, P.gk);
-    }
-    scaled[(size_t)frame * P.W * P.H + (size_t)dy * P.W + dx] = PSL_DADD(PSL_DMUL(h0, b0), PSL_DMUL(h1, b1));
-}
-
-// Tiled form of k_lsd_scale: a 64 x 16 tile of the working image needs <= 82 x 22 blurred samples,
-// i.e. <= 88 x 28 input pixels; they are staged once in LDS (reflect-101 applied while loading), row
-// sums and column sums are formed once per sample in the same operation order as above, and the
-// bilinear step reads the blurred tile.  ~9x fewer f64 operations than the per-pixel form.
 #define PSL_LS_IC 88
 #define PSL_LS_IR 28
 #define PSL_LS_BC 82
@@ -338,66 +297,7 @@ __global__ __launch_bounds__(256) void k_lsd_grad(LineParams P, const double* __
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// LSD steps 3-6: seeds in raster order, region growing (8-connected, running mean angle), rectangle
-// by inertia axes, density refinement.  The algorithm is a serial chain through `used` and the
-// running angle; one workgroup (one wave) owns one frame and parallelism comes from the frames of
-// the batch.  This first version runs the chain on lane 0.
-// ---------------------------------------------------------------------------------------------
-struct LsdRect { double x1, y1, x2, y2, width; };
-
-struct LsdFrame {
-    int W, H;
-    const float* ang;      // degrees, NOTDEF = -1024
-    const double* mod;
-    uint8_t* used;
-    uint32_t* reg;         // x | y << 16
-};
-
-__device__ __forceinline__ double psl_lsd_angle(const LsdFrame& F, int addr) { return PSL_DMUL((double)F.ang[addr], PSL_DEG2RAD); }
-
-__device__ __forceinline__ bool psl_lsd_aligned(const LsdFrame& F, int addr, double theta, double prec) {
-    const float ad = F.ang[addr];
-    if (ad == PSL_LSD_NOTDEF) return false;
-    double n_theta = PSL_DSUB(theta, PSL_DMUL((double)ad, PSL_DEG2RAD));
-    if (n_theta < 0) n_theta = -n_theta;
-    if (n_theta > (3 * PSL_PI) / 2) {
-        n_theta = PSL_DSUB(n_theta, 2 * PSL_PI);
-        if (n_theta < 0) n_theta = -n_theta;
-    }
-    return n_theta <= prec;
-}
-
-__device__ int psl_lsd_region_grow(const LsdFrame& F, int sx, int sy, double* reg_angle_out, double prec) {
-    int reg_size = 1;
-    const int addr0 = sx + sy * F.W;
-    F.reg[0] = (uint32_t)sx | ((uint32_t)sy << 16);
-    double reg_angle = psl_lsd_angle(F, addr0);
-    float sumdx = (float)cos(reg_angle), sumdy = (float)sin(reg_angle);
-    F.used[addr0] = 1;
-    for (int i = 0; i < reg_size; ++i) {
-        const uint32_t rp = F.reg[i];
-        const int px = (int)(rp & 0xffff), py = (int)(rp >> 16);
-        const int xx_min = max(px - 1, 0), xx_max = min(px + 1, F.W - 1);
-        const int yy_min = max(py - 1, 0), yy_max = min(py + 1, F.H - 1);
-        for (int yy = yy_min; yy <= yy_max; ++yy) {
-            int c = xx_min + yy * F.W;
-            for (int xx = xx_min; xx <= xx_max; ++xx, ++c) {
-                if (F.used[c] != 1 && psl_lsd_aligned(F, c, reg_angle, prec)) {
-                    F.used[c] = 1;
-                    F.reg[reg_size++] = (uint32_t)xx | ((uint32_t)yy << 16);
-                    float sn, cs;
-                    psl_sincosf((float)psl_lsd_angle(F, c), &sn, &cs);
-                    sumdx = PSL_FADD(sumdx, cs);
-                    sumdy = PSL_FADD(sumdy, sn);
-                    reg_angle = PSL_DMUL((double)psl_fast_atan2(sumdy, sumdx), PSL_DEG2RAD);
-                }
-            }
-        }
-    }
-    *reg_angle_out = reg_angle;
-    return reg_size;
-}
+struct LsdRect { double x1, y1, x2, y2, width, theta, dx, dy; };
 
 __device__ __forceinline__ double psl_angle_diff_signed(double a, double b) {
     double diff = PSL_DSUB(a, b);
@@ -411,158 +311,25 @@ __device__ __forceinline__ double psl_dist_sq(double x1, double y1, double x2, d
     return PSL_DADD(PSL_DMUL(dx, dx), PSL_DMUL(dy, dy));
 }
 
-__device__ void psl_lsd_region2rect(const LsdFrame& F, int reg_size, double reg_angle, double prec, LsdRect* rec) {
-    double x = 0, y = 0, sum = 0;
-    for (int i = 0; i < reg_size; ++i) {
-        const uint32_t rp = F.reg[i];
-        const int px = (int)(rp & 0xffff), py = (int)(rp >> 16);
-        const double w = F.mod[px + py * F.W];
-        x = PSL_DADD(x, PSL_DMUL((double)px, w));
-        y = PSL_DADD(y, PSL_DMUL((double)py, w));
-        sum = PSL_DADD(sum, w);
-    }
-    x = x / sum; y = y / sum;
-    // get_theta
-    double Ixx = 0, Iyy = 0, Ixy = 0;
-    for (int i = 0; i < reg_size; ++i) {
-        const uint32_t rp = F.reg[i];
-        const int px = (int)(rp & 0xffff), py = (int)(rp >> 16);
-        const double w = F.mod[px + py * F.W];
-        const double dx = PSL_DSUB((double)px, x), dy = PSL_DSUB((double)py, y);
-        Ixx = PSL_DADD(Ixx, PSL_DMUL(PSL_DMUL(dy, dy), w));
-        Iyy = PSL_DADD(Iyy, PSL_DMUL(PSL_DMUL(dx, dx), w));
-        Ixy = PSL_DSUB(Ixy, PSL_DMUL(PSL_DMUL(dx, dy), w));
-    }
-    const double dI = PSL_DSUB(Ixx, Iyy);
-    const double lambda = PSL_DMUL(0.5, PSL_DSUB(PSL_DADD(Ixx, Iyy), __dsqrt_rn(PSL_DADD(PSL_DMUL(dI, dI), PSL_DMUL(PSL_DMUL(4.0, Ixy), Ixy)))));
-    double theta = (fabs(Ixx) > fabs(Iyy)) ? (double)psl_fast_atan2((float)PSL_DSUB(lambda, Ixx), (float)Ixy)
-                                           : (double)psl_fast_atan2((float)Ixy, (float)PSL_DSUB(lambda, Iyy));
-    theta = PSL_DMUL(theta, PSL_DEG2RAD);
-    if (fabs(psl_angle_diff_signed(theta, reg_angle)) > prec) theta = PSL_DADD(theta, PSL_PI);
-    const double dx = cos(theta), dy = sin(theta);
-    double l_min = 0, l_max = 0, w_min = 0, w_max = 0;
-    for (int i = 0; i < reg_size; ++i) {
-        const uint32_t rp = F.reg[i];
-        const double rdx = PSL_DSUB((double)(int)(rp & 0xffff), x), rdy = PSL_DSUB((double)(int)(rp >> 16), y);
-        const double l = PSL_DADD(PSL_DMUL(rdx, dx), PSL_DMUL(rdy, dy));
-        const double w = PSL_DADD(PSL_DMUL(-rdx, dy), PSL_DMUL(rdy, dx));
-        if (l > l_max) l_max = l; else if (l < l_min) l_min = l;
-        if (w > w_max) w_max = w; else if (w < w_min) w_min = w;
-    }
-    rec->x1 = PSL_DADD(x, PSL_DMUL(l_min, dx)); rec->y1 = PSL_DADD(y, PSL_DMUL(l_min, dy));
-    rec->x2 = PSL_DADD(x, PSL_DMUL(l_max, dx)); rec->y2 = PSL_DADD(y, PSL_DMUL(l_max, dy));
-    rec->width = PSL_DSUB(w_max, w_min);
-    if (rec->width < 1.0) rec->width = 1.0;
-}
-
 __device__ __forceinline__ double psl_lsd_density(int reg_size, const LsdRect& r) {
     return (double)reg_size / PSL_DMUL(__dsqrt_rn(psl_dist_sq(r.x1, r.y1, r.x2, r.y2)), r.width);
 }
 
-// refine() + reduce_region_radius(); returns the final region size or 0 when the region is rejected
-__device__ int psl_lsd_refine(const LsdFrame& F, int reg_size, double reg_angle, double prec, LsdRect* rec, double density_th) {
-    double density = psl_lsd_density(reg_size, *rec);
-    if (density >= density_th) return reg_size;
-    const uint32_t r0 = F.reg[0];
-    const int x0 = (int)(r0 & 0xffff), y0 = (int)(r0 >> 16);
-    const double xc = (double)x0, yc = (double)y0;
-    const double ang_c = psl_lsd_angle(F, x0 + y0 * F.W);
-    double sum = 0, s_sum = 0;
-    int n = 0;
-    for (int i = 0; i < reg_size; ++i) {
-        const uint32_t rp = F.reg[i];
-        const int px = (int)(rp & 0xffff), py = (int)(rp >> 16);
-        F.used[px + py * F.W] = 0;
-        if (__dsqrt_rn(psl_dist_sq(xc, yc, (double)px, (double)py)) < rec->width) {
-            const double ang_d = psl_angle_diff_signed(psl_lsd_angle(F, px + py * F.W), ang_c);
-            sum = PSL_DADD(sum, ang_d);
-            s_sum = PSL_DADD(s_sum, PSL_DMUL(ang_d, ang_d));
-            ++n;
-        }
-    }
-    const double mean_angle = sum / (double)n;
-    const double tau = PSL_DMUL(2.0, __dsqrt_rn(PSL_DADD(PSL_DSUB(s_sum, PSL_DMUL(PSL_DMUL(2.0, mean_angle), sum)) / (double)n, PSL_DMUL(mean_angle, mean_angle))));
-    reg_size = psl_lsd_region_grow(F, x0, y0, &reg_angle, tau);
-    if (reg_size < 2) return 0;
-    psl_lsd_region2rect(F, reg_size, reg_angle, prec, rec);
-    density = psl_lsd_density(reg_size, *rec);
-    if (density >= density_th) return reg_size;
-    // reduce_region_radius
-    const double d1 = psl_dist_sq(xc, yc, rec->x1, rec->y1), d2 = psl_dist_sq(xc, yc, rec->x2, rec->y2);
-    double radSq = d1 > d2 ? d1 : d2;
-    while (density < density_th) {
-        radSq = PSL_DMUL(radSq, 0.75 * 0.75);
-        for (int i = 0; i < reg_size; ++i) {
-            const uint32_t rp = F.reg[i];
-            const int px = (int)(rp & 0xffff), py = (int)(rp >> 16);
-            if (psl_dist_sq(xc, yc, (double)px, (double)py) > radSq) {
-                F.used[px + py * F.W] = 0;
-                F.reg[i] = F.reg[reg_size - 1];
-                F.reg[reg_size - 1] = rp;
-                --reg_size;
-                --i;
-            }
-        }
-        if (reg_size < 2) return 0;
-        psl_lsd_region2rect(F, reg_size, reg_angle, prec, rec);
-        density = psl_lsd_density(reg_size, *rec);
-    }
-    return reg_size;
-}
-
-__global__ __launch_bounds__(64) void k_lsd_grow(LineParams P, const float* __restrict__ angdeg, const double* __restrict__ modgrad,
-                                                  uint8_t* __restrict__ used, uint32_t* __restrict__ reg, float* __restrict__ seg,
-                                                  int* __restrict__ nseg) {
-    const int frame = blockIdx.x;
-    const size_t npx = (size_t)P.W * P.H;
-    LsdFrame F;
-    F.W = P.W; F.H = P.H;
-    F.ang = angdeg + frame * npx; F.mod = modgrad + frame * npx; F.used = used + frame * npx; F.reg = reg + frame * npx;
-    for (size_t i = threadIdx.x; i < npx; i += 64) F.used[i] = 0;
-    __syncthreads();
-    if (threadIdx.x != 0) return;
-    float* out = seg + (size_t)frame * P.maxseg * 4;
-    int count = 0;
-    for (int y = 0; y < P.H - 1; ++y)
-        for (int x = 0; x < P.W - 1; ++x) {
-            const int adx = x + y * P.W;
-            if (F.used[adx] != 0 || F.ang[adx] == PSL_LSD_NOTDEF) continue;
-            double reg_angle;
-            int reg_size = psl_lsd_region_grow(F, x, y, &reg_angle, P.prec);
-            if (reg_size < P.min_reg_size) continue;
-            LsdRect rec;
-            psl_lsd_region2rect(F, reg_size, reg_angle, P.prec, &rec);
-            if (!psl_lsd_refine(F, reg_size, reg_angle, P.prec, &rec, 0.7)) continue;
-            if (count < P.maxseg) {
-                // +0.5 offset, /SCALE, float cast; then the contrib wrapper's checkLineExtremes
-                float e[4] = {(float)(PSL_DADD(rec.x1, 0.5) / 0.8), (float)(PSL_DADD(rec.y1, 0.5) / 0.8),
-                              (float)(PSL_DADD(rec.x2, 0.5) / 0.8), (float)(PSL_DADD(rec.y2, 0.5) / 0.8)};
-                if (e[0] < 0) e[0] = 0;
-                if (e[0] >= P.w) e[0] = (float)P.w - 1.0f;
-                if (e[2] < 0) e[2] = 0;
-                if (e[2] >= P.w) e[2] = (float)P.w - 1.0f;
-                if (e[1] < 0) e[1] = 0;
-                if (e[1] >= P.h) e[1] = (float)P.h - 1.0f;
-                if (e[3] < 0) e[3] = 0;
-                if (e[3] >= P.h) e[3] = (float)P.h - 1.0f;
-                out[4 * count] = e[0]; out[4 * count + 1] = e[1]; out[4 * count + 2] = e[2]; out[4 * count + 3] = e[3];
-            }
-            ++count;
-        }
-    nseg[frame] = count < P.maxseg ? count : P.maxseg;
-}
-
-
 // ---------------------------------------------------------------------------------------------
-// LSD steps 3-6, wave-parallel and still exact (k_lsd_grow2).  One wave owns one frame.
-//  * `used` map = bitmap in LDS;  the last 1024 queue entries are mirrored in an LDS ring;
+// LSD steps 3-6: seeds in raster order, region growing (8-connected, running mean angle), rectangle by
+// inertia axes, density refinement - wave-parallel and still exact (k_lsd_grow3).  The algorithm is a serial
+// chain through `used` and the running angle; one wave owns one frame and parallelism comes from the frames
+// of the batch.
 //  * seeds: 256 pixels per step (4 coalesced loads in flight), ballot -> first candidate;
 //  * region growing: up to 7 queue entries are popped together, lane = (entry, neighbour): the 63
-//    neighbour angles are loaded in ONE round trip and their cosf/sinf are evaluated speculatively in
-//    parallel; only the running-angle chain (add, fastAtan2) stays serial, in the reference's order;
+//    neighbour records are loaded in ONE round trip; only the running-angle chain (add, fastAtan2) stays
+//    serial, in the reference's order; the last 1024 queue entries are mirrored in an LDS ring;
 //  * sums whose rounding depends on the order (centroid, inertia, refine statistics) are formed as
 //    "terms in parallel, additions in series" (64 terms staged in LDS per step); min/max extents are
-//    order independent and use wave reductions.
+//    order independent and use wave reductions;
+//  * the `used` flag is the fourth word of the pixel's 16-byte record in HBM, written by lane 0 and read by
+//    the same wave only (workgroup scope: the CU's L1 is coherent for its own stores); inside a round every
+//    lane keeps its own "used" flag, updated by comparing its pixel with each pixel that is added.
 // Serial scalar logic is executed redundantly by all lanes (uniform values, no broadcasts); stores
 // are issued by lane 0.
 // ---------------------------------------------------------------------------------------------
@@ -572,114 +339,17 @@ struct LsdW {
     int W, H, lane;
     const float* ang;
     const double* mod;
-    float4* trig;          // (cosf, sinf, degrees | NOTDEF, used flag of k_lsd_grow3) per pixel
+    float4* trig;          // (cosf, sinf, degrees | NOTDEF, used flag) per pixel
     const float2* seedt;   // (float)cos, (float)sin of the double angle (seed pixels)
-    uint32_t* used;   // bitmap in LDS (k_lsd_grow2)
-    uint8_t* usedb;   // one byte per pixel in HBM (k_lsd_grow3, gused = true): plain byte stores instead of read-modify-write
-    bool gused;
     uint32_t* ring;   // LDS mirror of reg[idx & (RING-1)]
     double* term;     // LDS [3][64]
     uint32_t* reg;    // HBM queue
 };
 
-__device__ __forceinline__ bool lsdw_used(const LsdW& F, int a) { return (F.used[a >> 5] >> (a & 31)) & 1u; }
-__device__ __forceinline__ void lsdw_set(const LsdW& F, int a) { if (F.lane == 0) F.used[a >> 5] |= 1u << (a & 31); }
 __device__ __forceinline__ uint32_t lsdw_reg(const LsdW& F, int idx, int reg_size) {
     return (reg_size - idx <= PSL_LSD_RING) ? F.ring[idx & (PSL_LSD_RING - 1)] : F.reg[idx];
 }
-__device__ __forceinline__ void lsdw_push(const LsdW& F, int idx, uint32_t v) {
-    if (F.lane == 0) { F.reg[idx] = v; F.ring[idx & (PSL_LSD_RING - 1)] = v; }
-}
 
-__device__ __forceinline__ bool lsdw_aligned(double ad, double theta, double prec) {
-    double n_theta = PSL_DSUB(theta, ad);
-    if (n_theta < 0) n_theta = -n_theta;
-    if (n_theta > (3 * PSL_PI) / 2) {
-        n_theta = PSL_DSUB(n_theta, 2 * PSL_PI);
-        if (n_theta < 0) n_theta = -n_theta;
-    }
-    return n_theta <= prec;
-}
-
-__device__ int lsdw_region_grow(const LsdW& F, int sx, int sy, double* reg_angle_out, double prec) {
-    int reg_size = 1;
-    const int addr0 = sx + sy * F.W;
-    lsdw_push(F, 0, (uint32_t)sx | ((uint32_t)sy << 16));
-    double reg_angle = PSL_DMUL((double)F.ang[addr0], PSL_DEG2RAD);
-    const float2 t0 = F.seedt[addr0];
-    float sumdx = t0.x, sumdy = t0.y;  // float(cos(reg_angle)), float(sin(reg_angle))
-    lsdw_set(F, addr0);
-    const int e = F.lane / 9, k = F.lane - e * 9, ky = k / 3, kx = k - ky * 3;
-    // neighbour data of the entries popped in this round (cur) and, software-pipelined, of the entries the
-    // NEXT round will pop if they are already queued (nxt): their loads fly while this round's chain runs
-    float a_n = PSL_LSD_NOTDEF, cs_n = 0.f, sn_n = 0.f;
-    uint32_t xy_n = 0;
-    int pre = 0;
-    int i = 0;
-    while (i < reg_size) {
-        const int nb = min(7, reg_size - i);
-        float a = PSL_LSD_NOTDEF, sn = 0.f, cs = 0.f;
-        uint32_t xy = 0;  // nx | ny << 16
-        if (F.lane < 63 && e < nb) {
-            if (e < pre) { a = a_n; cs = cs_n; sn = sn_n; xy = xy_n; }
-            else {
-                const uint32_t rp = lsdw_reg(F, i + e, reg_size);
-                const int nx = (int)(rp & 0xffff) + kx - 1, ny = (int)(rp >> 16) + ky - 1;
-                if (nx >= 0 && nx < F.W && ny >= 0 && ny < F.H) {
-                    const int c = nx + ny * F.W;
-                    a = F.ang[c];
-                    const float2 t = *reinterpret_cast<const float2*>(&F.trig[c]);  // cosf, sinf of this pixel's angle
-                    cs = t.x; sn = t.y;
-                    xy = (uint32_t)nx | ((uint32_t)ny << 16);
-                }
-            }
-        }
-        pre = min(7, reg_size - (i + nb));
-        a_n = PSL_LSD_NOTDEF;
-        if (F.lane < 63 && e < pre) {
-            const uint32_t rp = lsdw_reg(F, i + nb + e, reg_size);
-            const int nx = (int)(rp & 0xffff) + kx - 1, ny = (int)(rp >> 16) + ky - 1;
-            if (nx >= 0 && nx < F.W && ny >= 0 && ny < F.H) {
-                const int c = nx + ny * F.W;
-                a_n = F.ang[c];
-                const float2 t = *reinterpret_cast<const float2*>(&F.trig[c]);
-                cs_n = t.x; sn_n = t.y;
-                xy_n = (uint32_t)nx | ((uint32_t)ny << 16);
-            }
-        }
-        const bool cand0 = a != PSL_LSD_NOTDEF;
-        const double ad = PSL_DMUL((double)a, PSL_DEG2RAD);
-        const int c = (int)(xy & 0xffff) + (int)(xy >> 16) * F.W;
-        // lanes are ordered (entry, neighbour) exactly as the reference visits them, so one cursor over the
-        // lane index replaces the per-entry loops: take the first lane >= cursor that is still unused and
-        // aligned with the CURRENT angle, add it, move the cursor behind it, re-test the rest.
-        int cursor = 0;
-        while (true) {
-            const bool ok = cand0 && F.lane >= cursor && !lsdw_used(F, c) && lsdw_aligned(ad, reg_angle, prec);
-            const unsigned long long m = __ballot(ok);
-            if (!m) break;
-            const int L = __ffsll((long long)m) - 1;  // wave-uniform: v_readlane instead of ds_bpermute
-            const uint32_t xyL = (uint32_t)__builtin_amdgcn_readlane((int)xy, L);
-            const float csL = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cs), L));
-            const float snL = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sn), L));
-            lsdw_set(F, (int)(xyL & 0xffff) + (int)(xyL >> 16) * F.W);
-            lsdw_push(F, reg_size, xyL);
-            ++reg_size;
-            sumdx = PSL_FADD(sumdx, csL);
-            sumdy = PSL_FADD(sumdy, snL);
-            reg_angle = PSL_DMUL((double)psl_fast_atan2(sumdy, sumdx), PSL_DEG2RAD);
-            cursor = L + 1;
-        }
-        i += nb;
-    }
-    *reg_angle_out = reg_angle;
-    return reg_size;
-}
-
-// ---- variant with the `used` flags in HBM ---------------------------------------------------------------
-// Frees the 24 KB of LDS per wave, so 6 waves per SIMD can overlap their serial chains.  The flag is the fourth word of the
-// pixel's 16-byte record, written by lane 0 and read by the same wave only (workgroup scope: the CU's L1 is coherent for its
-// own stores); inside a round every lane keeps its own "used" flag, updated by comparing its pixel with each pixel that is added.
 __device__ __forceinline__ bool lsdg_used(const LsdW& F, int a) {
     return __hip_atomic_load(reinterpret_cast<const uint32_t*>(&F.trig[a].w), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0;
 }
@@ -922,6 +592,7 @@ __device__ void lsdw_region2rect(const LsdW& F, int reg_size, double reg_angle, 
     rec->x2 = PSL_DADD(x, PSL_DMUL(l_max, dx)); rec->y2 = PSL_DADD(y, PSL_DMUL(l_max, dy));
     rec->width = PSL_DSUB(w_max, w_min);
     if (rec->width < 1.0) rec->width = 1.0;
+    rec->theta = theta; rec->dx = dx; rec->dy = dy;  // read by the NFA validation (LSD_REFINE_ADV) only
 }
 
 __device__ int lsdw_refine(const LsdW& F, int reg_size, double reg_angle, double prec, LsdRect* rec, double density_th) {
@@ -940,7 +611,7 @@ __device__ int lsdw_refine(const LsdW& F, int reg_size, double reg_angle, double
         if (j < reg_size) {
             const uint32_t rp = lsdw_reg(F, j, reg_size);
             const int px = (int)(rp & 0xffff), py = (int)(rp >> 16), a = px + py * F.W;
-            if (F.gused) lsdg_mark(F, a, 0); else atomicAnd(&F.used[a >> 5], ~(1u << (a & 31)));
+            lsdg_mark(F, a, 0);
             if (__dsqrt_rn(psl_dist_sq(xc, yc, (double)px, (double)py)) < rec->width) {
                 in = true;
                 ang_d = psl_angle_diff_signed(PSL_DMUL((double)F.ang[a], PSL_DEG2RAD), ang_c);
@@ -956,7 +627,7 @@ __device__ int lsdw_refine(const LsdW& F, int reg_size, double reg_angle, double
     const double sum = lsdw_lane_f64(acc, 0), s_sum = lsdw_lane_f64(acc, 1);
     const double mean_angle = sum / (double)n;
     const double tau = PSL_DMUL(2.0, __dsqrt_rn(PSL_DADD(PSL_DSUB(s_sum, PSL_DMUL(PSL_DMUL(2.0, mean_angle), sum)) / (double)n, PSL_DMUL(mean_angle, mean_angle))));
-    reg_size = F.gused ? lsdg_region_grow(F, x0, y0, &reg_angle, tau) : lsdw_region_grow(F, x0, y0, &reg_angle, tau);
+    reg_size = lsdg_region_grow(F, x0, y0, &reg_angle, tau);
     if (reg_size < 2) return 0;
     lsdw_region2rect(F, reg_size, reg_angle, prec, rec);
     density = psl_lsd_density(reg_size, *rec);
@@ -976,7 +647,7 @@ __device__ int lsdw_refine(const LsdW& F, int reg_size, double reg_angle, double
                 const int a = px + py * F.W;
                 const uint32_t last = F.reg[reg_size - 1];
                 if (F.lane == 0) {
-                    if (F.gused) lsdg_mark(F, a, 0); else atomicAnd(&F.used[a >> 5], ~(1u << (a & 31)));
+                    lsdg_mark(F, a, 0);
                     F.reg[i] = last; F.reg[reg_size - 1] = rp;
                 }
                 __builtin_amdgcn_wave_barrier();
@@ -996,65 +667,22 @@ __device__ int lsdw_refine(const LsdW& F, int reg_size, double reg_angle, double
     return reg_size;
 }
 
-__global__ __launch_bounds__(64) void k_lsd_grow2(LineParams P, const float* __restrict__ angdeg, const double* __restrict__ modgrad,
-                                                   float4* __restrict__ trig, const float2* __restrict__ seedt, uint32_t* __restrict__ reg,
-                                                   float* __restrict__ seg, int* __restrict__ nseg) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];  // used bitmap
-    __shared__ uint32_t s_ring[PSL_LSD_RING];
-    __shared__ double s_term[3 * 64];
-    const int frame = blockIdx.x, lane = threadIdx.x;
-    const size_t npx = (size_t)P.W * P.H;
-    const int words = (int)((npx + 31) >> 5);
-    LsdW F;
-    F.W = P.W; F.H = P.H; F.lane = lane;
-    F.ang = angdeg + frame * npx; F.mod = modgrad + frame * npx; F.trig = trig + frame * npx; F.reg = reg + frame * npx;
-    F.used = s_dyn; F.usedb = nullptr; F.seedt = seedt + frame * npx; F.gused = false; F.ring = s_ring; F.term = s_term;
-    for (int i = lane; i < words; i += 64) F.used[i] = 0;
-    __builtin_amdgcn_wave_barrier();
-    float* out = seg + (size_t)frame * P.maxseg * 4;
-    int count = 0;
-    const int scan_end = (P.H - 1) * P.W;  // rows 0 .. H-2
-    for (int base = 0; base < scan_end; base += 256) {
-        float a4[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { const int ad = base + q * 64 + lane; a4[q] = ad < scan_end ? F.ang[ad] : PSL_LSD_NOTDEF; }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int ad = base + q * 64 + lane;
-            unsigned long long mask = __ballot(a4[q] != PSL_LSD_NOTDEF);  // column W-1 and row H-1 are NOTDEF by construction
-            while (mask) {
-                const int s = __ffsll((long long)mask) - 1;
-                mask &= mask - 1;
-                const int adx = base + q * 64 + s;
-                if (lsdw_used(F, adx)) continue;
-                const int y = adx / P.W, x = adx - y * P.W;
-                double reg_angle;
-                int reg_size = lsdw_region_grow(F, x, y, &reg_angle, P.prec);
-                if (reg_size < P.min_reg_size) continue;
-                LsdRect rec;
-                lsdw_region2rect(F, reg_size, reg_angle, P.prec, &rec);
-                if (!lsdw_refine(F, reg_size, reg_angle, P.prec, &rec, 0.7)) continue;
-                if (count < P.maxseg && lane == 0) {
-                    float e[4] = {(float)(PSL_DADD(rec.x1, 0.5) / 0.8), (float)(PSL_DADD(rec.y1, 0.5) / 0.8),
-                                  (float)(PSL_DADD(rec.x2, 0.5) / 0.8), (float)(PSL_DADD(rec.y2, 0.5) / 0.8)};
-                    if (e[0] < 0) e[0] = 0;
-                    if (e[0] >= P.w) e[0] = (float)P.w - 1.0f;
-                    if (e[2] < 0) e[2] = 0;
-                    if (e[2] >= P.w) e[2] = (float)P.w - 1.0f;
-                    if (e[1] < 0) e[1] = 0;
-                    if (e[1] >= P.h) e[1] = (float)P.h - 1.0f;
-                    if (e[3] < 0) e[3] = 0;
-                    if (e[3] >= P.h) e[3] = (float)P.h - 1.0f;
-                    out[4 * count] = e[0]; out[4 * count + 1] = e[1]; out[4 * count + 2] = e[2]; out[4 * count + 3] = e[3];
-                }
-                ++count;
-            }
-            (void)ad;
-        }
-    }
-    if (lane == 0) nseg[frame] = count < P.maxseg ? count : P.maxseg;
-}
+#define PSL_LSD_RECT_F64 8   // doubles per rectangle record handed to the NFA kernel: x1 y1 x2 y2 width theta dx dy
 
+// flsd()'s output step (+0.5, / SCALE, to float) followed by the contrib wrapper's checkLineExtremes
+// (Thirdparty/line_descriptor/src/LSDDetector_custom.cpp:111-138)
+__device__ __forceinline__ void psl_lsd_store_segment(const LineParams& P, double x1, double y1, double x2, double y2, float* out) {
+    float e[4] = {(float)(PSL_DADD(x1, 0.5) / 0.8), (float)(PSL_DADD(y1, 0.5) / 0.8), (float)(PSL_DADD(x2, 0.5) / 0.8), (float)(PSL_DADD(y2, 0.5) / 0.8)};
+    if (e[0] < 0) e[0] = 0;
+    if (e[0] >= P.w) e[0] = (float)P.w - 1.0f;
+    if (e[2] < 0) e[2] = 0;
+    if (e[2] >= P.w) e[2] = (float)P.w - 1.0f;
+    if (e[1] < 0) e[1] = 0;
+    if (e[1] >= P.h) e[1] = (float)P.h - 1.0f;
+    if (e[3] < 0) e[3] = 0;
+    if (e[3] >= P.h) e[3] = (float)P.h - 1.0f;
+    out[0] = e[0]; out[1] = e[1]; out[2] = e[2]; out[3] = e[3];
+}
 
 #ifndef PSL_GROW_WAVES
 #define PSL_GROW_WAVES 6   // waves per SIMD the register budget allows: 6 (80 VGPRs, a few spills) with 6144 frames in flight is
@@ -1062,7 +690,7 @@ __global__ __launch_bounds__(64) void k_lsd_grow2(LineParams P, const float* __r
 #endif
 __global__ __launch_bounds__(64, PSL_GROW_WAVES) void k_lsd_grow3(LineParams P, const float* __restrict__ angdeg, const double* __restrict__ modgrad,
                                                    float4* __restrict__ trig, const float2* __restrict__ seedt, uint32_t* __restrict__ reg,
-                                                   float* __restrict__ seg, int* __restrict__ nseg) {
+                                                   float* __restrict__ seg, int* __restrict__ nseg, double* __restrict__ rects) {
     __shared__ uint32_t s_ring[PSL_LSD_RING];
     __shared__ double s_term[3 * 64];
     const int frame = blockIdx.x, lane = threadIdx.x;
@@ -1071,7 +699,7 @@ __global__ __launch_bounds__(64, PSL_GROW_WAVES) void k_lsd_grow3(LineParams P, 
     LsdW F;
     F.W = P.W; F.H = P.H; F.lane = lane;
     F.ang = angdeg + frame * npx; F.mod = modgrad + frame * npx; F.trig = trig + frame * npx; F.reg = reg + frame * npx;
-    F.used = nullptr; F.usedb = nullptr; F.seedt = seedt + frame * npx; F.gused = true; F.ring = s_ring; F.term = s_term;
+    F.seedt = seedt + frame * npx; F.ring = s_ring; F.term = s_term;
     // (the used flags start at 0: k_lsd_grad has just written the records)
     (void)words;
     float* out = seg + (size_t)frame * P.maxseg * 4;
@@ -1134,17 +762,12 @@ __global__ __launch_bounds__(64, PSL_GROW_WAVES) void k_lsd_grow3(LineParams P, 
                 lsdw_region2rect(F, reg_size, reg_angle, P.prec, &rec);
                 if (!lsdw_refine(F, reg_size, reg_angle, P.prec, &rec, 0.7)) continue;
                 if (count < P.maxseg && lane == 0) {
-                    float e[4] = {(float)(PSL_DADD(rec.x1, 0.5) / 0.8), (float)(PSL_DADD(rec.y1, 0.5) / 0.8),
-                                  (float)(PSL_DADD(rec.x2, 0.5) / 0.8), (float)(PSL_DADD(rec.y2, 0.5) / 0.8)};
-                    if (e[0] < 0) e[0] = 0;
-                    if (e[0] >= P.w) e[0] = (float)P.w - 1.0f;
-                    if (e[2] < 0) e[2] = 0;
-                    if (e[2] >= P.w) e[2] = (float)P.w - 1.0f;
-                    if (e[1] < 0) e[1] = 0;
-                    if (e[1] >= P.h) e[1] = (float)P.h - 1.0f;
-                    if (e[3] < 0) e[3] = 0;
-                    if (e[3] >= P.h) e[3] = (float)P.h - 1.0f;
-                    out[4 * count] = e[0]; out[4 * count + 1] = e[1]; out[4 * count + 2] = e[2]; out[4 * count + 3] = e[3];
+                    if (P.refine >= 2) {  // LSD_REFINE_ADV: the NFA validation never touches `used`, so it runs afterwards, one wave per rectangle
+                        double* r = rects + ((size_t)frame * P.maxseg + count) * PSL_LSD_RECT_F64;
+                        r[0] = rec.x1; r[1] = rec.y1; r[2] = rec.x2; r[3] = rec.y2; r[4] = rec.width; r[5] = rec.theta; r[6] = rec.dx; r[7] = rec.dy;
+                    } else {
+                        psl_lsd_store_segment(P, rec.x1, rec.y1, rec.x2, rec.y2, out + 4 * count);
+                    }
                 }
                 ++count;
             }

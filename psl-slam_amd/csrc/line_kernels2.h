@@ -3,8 +3,10 @@
 // Convention shared with the oracle: unqualified libm calls on float arguments in the reference
 // (atan, atan2, tan, sin, cos) are the float overloads; sinf/cosf are psl_sincosf (bit-identical to
 // glibc on [-2pi, 2pi]), atanf / atan2f are psl_atanf / psl_atan2f (glibc's float algorithms restated, pinned against libm);
-// tanf and the double sin/cos of MergeTwoLines come from the device math library (last-ulp differences vs glibc are possible
-// there; tolerance in the tests).
+// tanf is psl_tanf (glibc's float tanf restated, bit-identical for every float in [0, 120), psl_f64math.h); the double sin / cos
+// of MergeTwoLines are psl_cos_sin_f64 (fdlibm kernels, psl_sincos64.h: within 1 ulp of glibc, whose own table-driven algorithm is
+// not reproducible offline - the merged end points are rounded to float, so a last-ulp difference shows only if the double result
+// lies within ~1e-16 relative of a float rounding boundary).  Nothing here calls the device math library.
 #ifndef PSL_LINE_KERNELS2_H
 #define PSL_LINE_KERNELS2_H
 
@@ -90,7 +92,8 @@ __device__ void psl_merge_two_lines(const float* l1, const float* l2, float* out
         thr = PSL_DADD(PSL_DMUL(li, thi), PSL_DMUL(lj, tmp));
         thr = thr / PSL_DADD(li, lj);
     }
-    const double s = sin(thr), c = cos(thr);
+    double s, c;  // thr in [-pi/2, pi/2]: restricted-range evaluation (psl_sincos64.h), pinned against libm in the CPU suite
+    psl_cos_sin_f64(thr, &c, &s);
     const double axg = PSL_DADD(PSL_DMUL(PSL_DSUB((double)ay, yg), s), PSL_DMUL(PSL_DSUB((double)ax, xg), c));
     const double bxg = PSL_DADD(PSL_DMUL(PSL_DSUB((double)by, yg), s), PSL_DMUL(PSL_DSUB((double)bx, xg), c));
     const double cxg = PSL_DADD(PSL_DMUL(PSL_DSUB((double)cy, yg), s), PSL_DMUL(PSL_DSUB((double)cx, xg), c));
@@ -860,7 +863,7 @@ __global__ __launch_bounds__(256) void k_lil_pair(const float* __restrict__ line
         const float dy = PSL_FSUB(p3, p1), dx = PSL_FSUB(p2, p0);
         const float degAng = psl_fast_atan2(dy, dx);
         const float arcAng = (float)PSL_DMUL((double)(degAng / 180), PSL_PI);
-        const float length = __builtin_fabsf(tanf(arcAng)) > 1 ? __builtin_fabsf(dy) : __builtin_fabsf(dx);
+        const float length = __builtin_fabsf(psl_tanf(arcAng)) > 1 ? __builtin_fabsf(dy) : __builtin_fabsf(dx);
         const int th = (int)PSL_FMUL(radius, 2.f), tw = (int)PSL_FADD(length, PSL_FMUL(2.f, radius));  // CvSize is integer
         const float hafW = (float)tw / 2, hafH = (float)th / 2;
         const float angle = (float)(PSL_DMUL((double)degAng, PSL_PI) / 180);

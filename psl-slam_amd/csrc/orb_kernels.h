@@ -15,8 +15,6 @@
 
 #define PSL_EDGE 16          // minBorderX = EDGE_THRESHOLD - 3 (src/ORBextractor.cc:773)
 #define PSL_MAXCELL 64       // largest FAST cell interior handled by k_fast_cells
-#define PSL_FAST_TP 76       // LDS pitch of the (cell+6)^2 image tile (+3 alignment slack, multiple of 4)
-#define PSL_FAST_SP 68       // LDS pitch of the (cell+2)^2 score map
 
 struct OrbLevelP {
     int w, h, pitch;            // level image (levels >= 1 live in the pyramid block)
@@ -75,52 +73,12 @@ __device__ __forceinline__ const uint8_t* psl_level_ptr(const OrbParams& P, cons
 // ---------------------------------------------------------------------------------------------
 // Pyramid: level l from level l-1, cv::resize INTER_LINEAR 8UC1 fixed point (Appendix A.3).
 // Tables (xofs, alpha, yofs, beta) are built on the host exactly as OpenCV builds them.
-// One thread = 4 horizontally adjacent output pixels (one dword store).
-// ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_pyr_resize(OrbParams P, FrameSrc S, int level,
-                                                     const int* __restrict__ xofs, const short2* __restrict__ alpha,
-                                                     const int* __restrict__ yofs, const short2* __restrict__ beta) {
-    const OrbLevelP L = P.lv[level];
-    const int frame = blockIdx.z;
-    const int dy = blockIdx.y * 4 + (threadIdx.x >> 6);
-    const int x4 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
-    if (dy >= L.h || x4 >= L.pitch) return;
-    int spitch;
-    const uint8_t* src = psl_level_ptr(P, S, level - 1, frame, &spitch);
-    const int sw = P.lv[level - 1].w, sh = P.lv[level - 1].h;
-    uint8_t* dst = S.pyr + (size_t)frame * S.pyr_fstride + L.img_off + (size_t)dy * L.pitch;
-    int sy0 = yofs[dy], sy1 = sy0 + 1;
-    sy0 = sy0 < 0 ? 0 : (sy0 >= sh ? sh - 1 : sy0);
-    sy1 = sy1 < 0 ? 0 : (sy1 >= sh ? sh - 1 : sy1);
-    const short2 b = beta[dy];
-    const uint8_t* r0 = src + (size_t)sy0 * spitch;
-    const uint8_t* r1 = src + (size_t)sy1 * spitch;
-    uint32_t packed = 0;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        int dx = x4 + j;
-        dx = dx < L.w ? dx : L.w - 1;  // padding columns repeat the last pixel
-        const int sx = xofs[dx];
-        const short2 a = alpha[dx];
-        int h0, h1;
-        if (sx + 1 < sw) {
-            h0 = r0[sx] * a.x + r0[sx + 1] * a.y;
-            h1 = r1[sx] * a.x + r1[sx + 1] * a.y;
-        } else {
-            h0 = r0[sx] * 2048;
-            h1 = r1[sx] * 2048;
-        }
-        const int v = ((((int)b.x * (h0 >> 4)) >> 16) + (((int)b.y * (h1 >> 4)) >> 16) + 2) >> 2;
-        packed |= (uint32_t)(v & 0xff) << (8 * j);
-    }
-    *reinterpret_cast<uint32_t*>(dst + x4) = packed;
-}
-
-// Same arithmetic, source staged through LDS: a workgroup produces a 64 x 32 block of the level and first
+// The source is staged through LDS: a workgroup produces a 64 x 32 block of the level and first
 // copies the source rectangle it needs (<= PSL_PYR_TR rows of <= PSL_PYR_TD dwords) with coalesced dword
 // loads; the taps of a thread then come from LDS instead of scattered byte loads from HBM/L2.  A thread makes
 // 4 adjacent pixels of two rows (16 apart), sharing the column tables; all table loads are issued before the
 // tile loads so that the workgroup pays two memory round trips, not three.
+// ---------------------------------------------------------------------------------------------
 typedef unsigned short pyr_u16x2 __attribute__((ext_vector_type(2)));
 #define PSL_PYR_TD 36   // tile pitch in dwords
 #define PSL_PYR_TR 48   // tile rows
@@ -257,172 +215,7 @@ __global__ __launch_bounds__(256) void k_pyr_resize_tiled(OrbParams P, FrameSrc 
 //   a neighbour below t has S(q) < t <= S(p) anyway.
 // Survivors are written in raster order: x | y << 12 | S << 24, (x, y) relative to minBorder.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ int psl_fast_score(const uint8_t* c, const int tp) {
-    const int v = c[0];
-    int d[16];
-    d[0] = v - c[3 * tp];       d[1] = v - c[3 * tp + 1];   d[2] = v - c[2 * tp + 2];   d[3] = v - c[tp + 3];
-    d[4] = v - c[3];            d[5] = v - c[-tp + 3];      d[6] = v - c[-2 * tp + 2];  d[7] = v - c[-3 * tp + 1];
-    d[8] = v - c[-3 * tp];      d[9] = v - c[-3 * tp - 1];  d[10] = v - c[-2 * tp - 2]; d[11] = v - c[-tp - 3];
-    d[12] = v - c[-3];          d[13] = v - c[tp - 3];      d[14] = v - c[2 * tp - 2];  d[15] = v - c[3 * tp - 1];
-    int lo2[16], hi2[16], lo4[16], hi4[16];
-#pragma unroll
-    for (int k = 0; k < 16; ++k) { lo2[k] = min(d[k], d[(k + 1) & 15]); hi2[k] = max(d[k], d[(k + 1) & 15]); }
-#pragma unroll
-    for (int k = 0; k < 16; ++k) { lo4[k] = min(lo2[k], lo2[(k + 2) & 15]); hi4[k] = max(hi2[k], hi2[(k + 2) & 15]); }
-    int A = -256, B = 256;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        const int lo9 = min(min(lo4[k], lo4[(k + 4) & 15]), d[(k + 8) & 15]);
-        const int hi9 = max(max(hi4[k], hi4[(k + 4) & 15]), d[(k + 8) & 15]);
-        A = max(A, lo9);
-        B = min(B, hi9);
-    }
-    return max(A, -B) - 1;
-}
-
-__global__ __launch_bounds__(256, 8) void k_fast_cells(OrbParams P, FrameSrc S, int* __restrict__ cellcnt,
-                                                     uint32_t* __restrict__ cellcand) {
-    __shared__ __attribute__((aligned(16))) uint8_t s_tile[(PSL_MAXCELL + 6) * PSL_FAST_TP + 8];
-    __shared__ uint8_t s_score[(PSL_MAXCELL + 2) * PSL_FAST_SP];
-    __shared__ int s_cnt[2][64];  // survivors per (pass, wave) at iniTh / minTh
-    __shared__ int s_off[2][65];
-    __shared__ uint16_t s_list[PSL_MAXCELL * PSL_MAXCELL];  // pixels that pass the quick corner test
-    __shared__ int s_nlist;
-
-    const int cell = blockIdx.x, frame = blockIdx.y;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    int level = 0;
-    while (level + 1 < P.nlevels && cell >= P.lv[level + 1].cell_off) ++level;
-    const OrbLevelP L = P.lv[level];
-    const int ci = cell - L.cell_off;
-    const int i = ci / L.nCols, j = ci - i * L.nCols;
-    int* out_cnt = cellcnt + (size_t)frame * P.ncells + cell;
-    uint32_t* out = cellcand + ((size_t)frame * P.ncells + cell) * P.cellcap;
-
-    // cell window, src/ORBextractor.cc:789-806 (all quantities are integers held in floats there)
-    const int iniY = PSL_EDGE + i * L.hCell, iniX = PSL_EDGE + j * L.wCell;
-    int maxY = iniY + L.hCell + 6, maxX = iniX + L.wCell + 6;
-    if (maxY > L.maxBY) maxY = L.maxBY;
-    if (maxX > L.maxBX) maxX = L.maxBX;
-    const int tw = maxX - iniX, th = maxY - iniY;
-    if (iniY >= L.maxBY - 3 || iniX >= L.maxBX - 6 || tw < 7 || th < 7) {
-        if (tid == 0) *out_cnt = 0;
-        return;
-    }
-    const int iw = tw - 6, ih = th - 6;
-
-    int pitch;
-    const uint8_t* img = psl_level_ptr(P, S, level, frame, &pitch);
-    // tile rows as aligned dwords when the level's rows are 4-byte aligned (always for levels >= 1): the
-    // tile then starts `toff` bytes into its first dword
-    const bool aligned4 = ((reinterpret_cast<uintptr_t>(img) | (uintptr_t)pitch) & 3) == 0;
-    const int toff = aligned4 ? (iniX & 3) : 0;
-    if (aligned4) {
-        const int ndw = (toff + tw + 3) >> 2;  // <= 19
-        for (int k = tid; k < th * ndw; k += 256) {
-            const int y = k / ndw, d = k - y * ndw;
-            reinterpret_cast<uint32_t*>(s_tile)[y * (PSL_FAST_TP / 4) + d] =
-                *reinterpret_cast<const uint32_t*>(img + (size_t)(iniY + y) * pitch + (iniX - toff) + d * 4);
-        }
-    } else {
-        for (int y = wave; y < th; y += 4) {
-            const uint8_t* row = img + (size_t)(iniY + y) * pitch + iniX;
-            for (int x = lane; x < tw; x += 64) s_tile[y * PSL_FAST_TP + x] = row[x];
-        }
-    }
-    for (int k = tid; k < (ih + 2) * PSL_FAST_SP; k += 256) s_score[k] = 0;
-    if (tid < 128) (&s_cnt[0][0])[tid] = 0;
-    if (tid == 0) s_nlist = 0;
-    __syncthreads();
-
-    const int npix = iw * ih;
-    const int npass = (npix + 255) >> 8;
-    const int minTh = P.minTh, iniTh = P.iniTh;
-    // Quick reject (exact necessary condition): an arc of 9 contains one pixel of every opposite pair, so a
-    // pixel with S >= minTh has, for the 4 pairs (0,8) (2,10) (4,12) (6,14), one member > v+minTh in each
-    // pair or one member < v-minTh in each pair.  Survivors (a few % of the pixels) are compacted and
-    // only they pay for the full score.
-    for (int p = 0; p < npass; ++p) {
-        const int idx = p * 256 + tid;
-        bool pass = false;
-        if (idx < npix) {
-            const int y = idx / iw, x = idx - y * iw;
-            const uint8_t* c = &s_tile[(y + 3) * PSL_FAST_TP + x + 3 + toff];
-            const int hi = c[0] + minTh, lo = c[0] - minTh;
-            const int r0 = c[3 * PSL_FAST_TP], r8 = c[-3 * PSL_FAST_TP], r4 = c[3], r12 = c[-3];
-            const int r2 = c[2 * PSL_FAST_TP + 2], r10 = c[-2 * PSL_FAST_TP - 2], r6 = c[-2 * PSL_FAST_TP + 2], r14 = c[2 * PSL_FAST_TP - 2];
-            const bool b = ((r0 > hi) | (r8 > hi)) & ((r4 > hi) | (r12 > hi)) & ((r2 > hi) | (r10 > hi)) & ((r6 > hi) | (r14 > hi));
-            const bool d = ((r0 < lo) | (r8 < lo)) & ((r4 < lo) | (r12 < lo)) & ((r2 < lo) | (r10 < lo)) & ((r6 < lo) | (r14 < lo));
-            pass = b | d;
-        }
-        const unsigned long long m = __ballot(pass);
-        int base = 0;
-        if (lane == 0 && m) base = atomicAdd(&s_nlist, __popcll(m));
-        base = __shfl(base, 0);
-        if (pass) s_list[base + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)idx;
-    }
-    __syncthreads();
-    const int nlist = s_nlist;
-    for (int i = tid; i < nlist; i += 256) {
-        const int idx = s_list[i];
-        const int y = idx / iw, x = idx - y * iw;
-        int s = psl_fast_score(&s_tile[(y + 3) * PSL_FAST_TP + x + 3 + toff], PSL_FAST_TP);
-        s = s < minTh ? 0 : (s > 255 ? 255 : s);
-        s_score[(y + 1) * PSL_FAST_SP + x + 1] = (uint8_t)s;
-    }
-    __syncthreads();
-
-    uint32_t keep_ini = 0, keep_min = 0;  // bit p: this thread's pixel of pass p survives
-    for (int p = 0; p < npass; ++p) {
-        const int idx = p * 256 + tid;
-        bool f_min = false, f_ini = false;
-        if (idx < npix) {
-            const int y = idx / iw, x = idx - y * iw;
-            const uint8_t* c = &s_score[(y + 1) * PSL_FAST_SP + x + 1];
-            const int s = c[0];
-            if (s > 0) {
-                const int m = max(max(max(c[-1], c[1]), max(c[-PSL_FAST_SP - 1], c[-PSL_FAST_SP])),
-                                  max(max(c[-PSL_FAST_SP + 1], c[PSL_FAST_SP - 1]), max(c[PSL_FAST_SP], c[PSL_FAST_SP + 1])));
-                f_min = s > m;
-                f_ini = f_min && s >= iniTh;
-            }
-        }
-        const unsigned long long b_min = __ballot(f_min), b_ini = __ballot(f_ini);
-        if (lane == 0) { s_cnt[0][p * 4 + wave] = __popcll(b_ini); s_cnt[1][p * 4 + wave] = __popcll(b_min); }
-        keep_ini |= (uint32_t)f_ini << p;
-        keep_min |= (uint32_t)f_min << p;
-    }
-    __syncthreads();
-    if (wave == 0) {  // exclusive scan of the 64 (pass, wave) counts, both thresholds
-        for (int t = 0; t < 2; ++t) {
-            const int v = s_cnt[t][lane];
-            int inc = v;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(inc, o); if (lane >= o) inc += u; }
-            s_off[t][lane] = inc - v;
-            if (lane == 63) s_off[t][64] = inc;
-        }
-    }
-    __syncthreads();
-    const int use = s_off[0][64] > 0 ? 0 : 1;  // retry at minTh only if iniTh found nothing (:812-816)
-    const int total = s_off[use][64];
-    const uint32_t keep = use == 0 ? keep_ini : keep_min;
-    for (int p = 0; p < npass; ++p) {
-        const bool f = (keep >> p) & 1;
-        const unsigned long long b = __ballot(f);
-        if (f) {
-            const int idx = p * 256 + tid;
-            const int y = idx / iw, x = idx - y * iw;
-            const int pos = s_off[use][p * 4 + wave] + __popcll(b & ((1ull << lane) - 1ull));
-            const uint32_t s = s_score[(y + 1) * PSL_FAST_SP + x + 1];
-            if (pos < P.cellcap)
-                out[pos] = (uint32_t)(x + 3 + j * L.wCell) | ((uint32_t)(y + 3 + i * L.hCell) << 12) | (s << 24);
-        }
-    }
-    if (tid == 0) *out_cnt = total < P.cellcap ? total : P.cellcap;
-}
-
-// k_fast_cells4: same results as k_fast_cells; dense work only where it is needed.
+// k_fast_cells4: dense work only where it is needed.
 //   * the tile is stored with interior column 0 at a dword boundary (tile byte = 1 + tile x), shifting the
 //     global dwords with v_alignbyte on the way in, so the 9 ring samples of the quick test for 4 pixels come
 //     from 11 aligned LDS dword reads (+ 6 alignbyte) instead of 36 byte reads; four horizontally adjacent
@@ -456,7 +249,6 @@ __device__ __forceinline__ int psl_fast_score_pol(const uint8_t* c, const int tp
     return A - 1;
 }
 
-template <int PART>  // 0: the launch for the level-0 cells that runs beside the pyramid; 1: any other launch (separate names in profiles)
 __global__ __launch_bounds__(256, 8) void k_fast_cells4(OrbParams P, FrameSrc S, const uint32_t* __restrict__ celltab,
                                                       int* __restrict__ cellcnt, uint32_t* __restrict__ cellcand, int cell_begin) {
     __shared__ __attribute__((aligned(16))) uint32_t s_tile32[(PSL_MAXCELL + 6) * (PSL_FAST4_TP / 4) + 4];

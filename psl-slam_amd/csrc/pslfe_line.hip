@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "line_kernels2.h"
+#include "line_kernels3.h"
 #include "pslfe_internal.h"
 
 struct pslfe_line {
@@ -15,6 +16,7 @@ struct pslfe_line {
     int numOctaves = 1, nfeatures = 200, max_batch = 1;
     float scale = 1.2f;
     double min_line_length = 0;
+    int refine = 2;  // LSD_REFINE_ADV (what the stock contrib LSDDetector constructs), 1 = LSD_REFINE_STD: pslfe_line_set_refine
     std::vector<float> scaleF, invScaleF, sigma2, invSigma2;
 
     int gw = 0, gh = 0;
@@ -29,9 +31,11 @@ struct pslfe_line {
     double* d_modgrad = nullptr;
     float4* d_trig = nullptr;
     float2* d_seedt = nullptr;
-    uint8_t* d_used = nullptr;
-    uint32_t* d_usedbits = nullptr;
     uint32_t* d_reg = nullptr;
+    double* d_rects = nullptr;    // LSD_REFINE_ADV: rectangles of k_lsd_grow3 for k_lsd_nfa
+    int* d_nrect = nullptr;
+    float* d_segtmp = nullptr;
+    uint8_t* d_keep = nullptr;
     float* d_seg = nullptr;
     int* d_nseg = nullptr;
     MergeScratch M = {};
@@ -57,11 +61,21 @@ struct pslfe_line {
         d_rawfans = nullptr; d_fans = nullptr; d_nfans = nullptr; d_tmplines = nullptr;
         hipFree(d_trig); d_trig = nullptr;
         hipFree(d_seedt); d_seedt = nullptr;
-        hipFree(d_usedbits); d_usedbits = nullptr;
-        hipFree(d_in); hipFree(d_scaled); hipFree(d_angdeg); hipFree(d_modgrad); hipFree(d_used); hipFree(d_reg);
-        hipFree(d_seg); hipFree(d_nseg);
-        d_in = nullptr; d_scaled = nullptr; d_angdeg = nullptr; d_modgrad = nullptr; d_used = nullptr; d_reg = nullptr;
-        d_seg = nullptr; d_nseg = nullptr;
+        hipFree(d_in); hipFree(d_scaled); hipFree(d_angdeg); hipFree(d_modgrad); hipFree(d_reg);
+        hipFree(d_seg); hipFree(d_nseg); hipFree(d_rects); hipFree(d_nrect); hipFree(d_segtmp); hipFree(d_keep);
+        d_in = nullptr; d_scaled = nullptr; d_angdeg = nullptr; d_modgrad = nullptr; d_reg = nullptr;
+        d_seg = nullptr; d_nseg = nullptr; d_rects = nullptr; d_nrect = nullptr; d_segtmp = nullptr; d_keep = nullptr;
+        gw = gh = 0;   // no geometry is prepared any more: the next call allocates again (or fails again) instead of
+        last_nframes = 0;  // launching on freed memory
+    }
+
+    // allocation failure inside prepare(): leave the object empty, not half-built (the early return `w == gw && h == gh` of the
+    // next call must not see the old geometry with freed or undersized buffers)
+    int fail_prepare(hipError_t e, const char* what) {
+        release();
+        (void)hipGetLastError();
+        pslfe_set_error("line: allocating %s for %d frames failed: %s", what, max_batch, hipGetErrorString(e));
+        return PSLFE_E_HIP;
     }
 
     int prepare(int w, int h) {
@@ -97,6 +111,8 @@ struct pslfe_line {
         }
         const double LOG_NT = 5 * (log10((double)Q.W) + log10((double)Q.H)) / 2 + log10(11.0);
         Q.min_reg_size = (int)(size_t)(-LOG_NT / log10(Q.p));
+        Q.log_nt = LOG_NT;
+        Q.refine = refine;
         {   // 8-bit GaussianBlur 5x5 sigma 1 -> integer kernel (OpenCV 3.2)
             float cf[5];
             double sum = 0;
@@ -113,46 +129,55 @@ struct pslfe_line {
         }
         PSL_HIP(hipSetDevice(ctx->device));
         PSL_HIP(hipStreamSynchronize(ctx->stream));
-        release();
+        release();  // also forgets the old geometry: a failure below leaves an empty object, never a half-built one
+#define PSL_ALLOC(ptr, bytes)                                                   \
+    do {                                                                        \
+        const hipError_t e_ = hipMalloc((void**)&(ptr), (bytes));               \
+        if (e_ != hipSuccess) return fail_prepare(e_, #ptr);                    \
+    } while (0)
         const size_t F = (size_t)max_batch, npx = (size_t)Q.W * Q.H;
         in_pitch = (int)psl_align_up(w, 16);
         in_fstride = psl_align_up((size_t)in_pitch * h, 256);
-        PSL_HIP(hipMalloc((void**)&d_in, in_fstride * F));
-        PSL_HIP(hipMalloc((void**)&d_scaled, npx * F * sizeof(double)));
-        PSL_HIP(hipMalloc((void**)&d_angdeg, npx * F * sizeof(float)));
-        PSL_HIP(hipMalloc((void**)&d_modgrad, npx * F * sizeof(double)));
-        PSL_HIP(hipMalloc((void**)&d_trig, npx * F * sizeof(float4)));
-        PSL_HIP(hipMalloc((void**)&d_seedt, npx * F * sizeof(float2)));
-        PSL_HIP(hipMalloc((void**)&d_used, npx * F));
-        PSL_HIP(hipMalloc((void**)&d_reg, npx * F * sizeof(uint32_t)));
-        PSL_HIP(hipMalloc((void**)&d_seg, (size_t)Q.maxseg * 4 * sizeof(float) * F));
-        PSL_HIP(hipMalloc((void**)&d_nseg, F * sizeof(int)));
+        PSL_ALLOC(d_in, in_fstride * F);
+        PSL_ALLOC(d_scaled, npx * F * sizeof(double));
+        PSL_ALLOC(d_angdeg, npx * F * sizeof(float));
+        PSL_ALLOC(d_modgrad, npx * F * sizeof(double));
+        PSL_ALLOC(d_trig, npx * F * sizeof(float4));
+        PSL_ALLOC(d_seedt, npx * F * sizeof(float2));
+        PSL_ALLOC(d_reg, npx * F * sizeof(uint32_t));
+        PSL_ALLOC(d_seg, (size_t)Q.maxseg * 4 * sizeof(float) * F);
+        PSL_ALLOC(d_nseg, F * sizeof(int));
+        PSL_ALLOC(d_rects, (size_t)Q.maxseg * PSL_LSD_RECT_F64 * sizeof(double) * F);
+        PSL_ALLOC(d_nrect, F * sizeof(int));
+        PSL_ALLOC(d_segtmp, (size_t)Q.maxseg * 4 * sizeof(float) * F);
+        PSL_ALLOC(d_keep, (size_t)Q.maxseg * F);
         const size_t N = PSL_MERGE_NMAX;
-        PSL_HIP(hipMalloc((void**)&M.lines0, F * N * 4 * sizeof(float)));
-        PSL_HIP(hipMalloc((void**)&M.lines1, F * N * 4 * sizeof(float)));
-        PSL_HIP(hipMalloc((void**)&M.merged, F * N * 4 * sizeof(float)));
-        PSL_HIP(hipMalloc((void**)&M.angles, F * N * sizeof(float)));
-        PSL_HIP(hipMalloc((void**)&M.length, F * N * sizeof(float)));
-        PSL_HIP(hipMalloc((void**)&M.order, F * N * sizeof(int)));
-        PSL_HIP(hipMalloc((void**)&M.pos, F * N * sizeof(int)));
-        PSL_HIP(hipMalloc((void**)&M.adj, F * N * (N / 32) * sizeof(uint32_t)));
-        PSL_HIP(hipMalloc((void**)&M.code, F * N * sizeof(int)));
-        PSL_HIP(hipMalloc((void**)&M.clist, F * PSL_MERGE_CLMAX * sizeof(int)));
-        PSL_HIP(hipMalloc((void**)&M.coff, F * (2 * N + 2) * sizeof(int)));
-        PSL_HIP(hipMalloc((void**)&M.work, F * 4 * N * sizeof(int)));
-        PSL_HIP(hipMalloc((void**)&M.bits, F * (N / 32) * sizeof(uint32_t)));
-        PSL_HIP(hipMalloc((void**)&M.stage, F * N * sizeof(PslKeyLine)));
-        PSL_HIP(hipMalloc((void**)&d_kls, F * Q.maxkl * sizeof(PslKeyLine)));
-        PSL_HIP(hipMalloc((void**)&d_ldesc, F * Q.maxkl * 32));
-        PSL_HIP(hipMalloc((void**)&d_fdesc, F * Q.maxkl * 72 * sizeof(float)));
-        PSL_HIP(hipMalloc((void**)&d_lineEq, F * Q.maxkl * 3 * sizeof(double)));
-        PSL_HIP(hipMalloc((void**)&d_nkl, F * sizeof(int)));
-        PSL_HIP(hipMalloc((void**)&d_status, F * sizeof(int)));
-        PSL_HIP(hipMalloc((void**)&d_dxy, F * (size_t)w * h * sizeof(short2)));
-        PSL_HIP(hipMalloc((void**)&d_rawfans, F * PSL_FAN_CAP * 4 * sizeof(float)));
-        PSL_HIP(hipMalloc((void**)&d_fans, F * PSL_FAN_CAP * 4 * sizeof(float)));
-        PSL_HIP(hipMalloc((void**)&d_nfans, F * sizeof(int)));
-        PSL_HIP(hipMalloc((void**)&d_tmplines, N * 4 * sizeof(float)));
+        PSL_ALLOC(M.lines0, F * N * 4 * sizeof(float));
+        PSL_ALLOC(M.lines1, F * N * 4 * sizeof(float));
+        PSL_ALLOC(M.merged, F * N * 4 * sizeof(float));
+        PSL_ALLOC(M.angles, F * N * sizeof(float));
+        PSL_ALLOC(M.length, F * N * sizeof(float));
+        PSL_ALLOC(M.order, F * N * sizeof(int));
+        PSL_ALLOC(M.pos, F * N * sizeof(int));
+        PSL_ALLOC(M.adj, F * N * (N / 32) * sizeof(uint32_t));
+        PSL_ALLOC(M.code, F * N * sizeof(int));
+        PSL_ALLOC(M.clist, F * PSL_MERGE_CLMAX * sizeof(int));
+        PSL_ALLOC(M.coff, F * (2 * N + 2) * sizeof(int));
+        PSL_ALLOC(M.work, F * 4 * N * sizeof(int));
+        PSL_ALLOC(M.bits, F * (N / 32) * sizeof(uint32_t));
+        PSL_ALLOC(M.stage, F * N * sizeof(PslKeyLine));
+        PSL_ALLOC(d_kls, F * Q.maxkl * sizeof(PslKeyLine));
+        PSL_ALLOC(d_ldesc, F * Q.maxkl * 32);
+        PSL_ALLOC(d_fdesc, F * Q.maxkl * 72 * sizeof(float));
+        PSL_ALLOC(d_lineEq, F * Q.maxkl * 3 * sizeof(double));
+        PSL_ALLOC(d_nkl, F * sizeof(int));
+        PSL_ALLOC(d_status, F * sizeof(int));
+        PSL_ALLOC(d_dxy, F * (size_t)w * h * sizeof(short2));
+        PSL_ALLOC(d_rawfans, F * PSL_FAN_CAP * 4 * sizeof(float));
+        PSL_ALLOC(d_fans, F * PSL_FAN_CAP * 4 * sizeof(float));
+        PSL_ALLOC(d_nfans, F * sizeof(int));
+        PSL_ALLOC(d_tmplines, N * 4 * sizeof(float));
+#undef PSL_ALLOC
         P = Q;
         gw = w; gh = h;
         last_nframes = 0;
@@ -165,17 +190,11 @@ struct pslfe_line {
         PSL_HIP(hipSetDevice(ctx->device));
         hipStream_t st = ctx->stream;
         const unsigned F = (unsigned)nframes;
-        dim3 grid((P.W + 63) / 64, (P.H + 3) / 4, F);
         {
             PSL_STAGE_BEGIN(ctx, "line.lsd_scale");
-            if (getenv("PSLFE_LSD_SCALE_SIMPLE"))
-                k_lsd_scale<<<grid, 256, 0, st>>>(P, d_gray, stride, frame_stride, d_scaled);
-            else
-            {
-                const unsigned tx = (P.W + 63) / 64, ty = (P.H + 15) / 16;
-                const int xcd = F >= 8 ? 1 : 0;
-                k_lsd_scale_tiled<<<xcd ? dim3(8, tx * ty, (F + 7) / 8) : dim3(tx, ty, F), 256, 0, st>>>(P, d_gray, stride, frame_stride, d_scaled, (int)F, xcd);
-            }
+            const unsigned tx = (P.W + 63) / 64, ty = (P.H + 15) / 16;
+            const int xcd = F >= 8 ? 1 : 0;
+            k_lsd_scale_tiled<<<xcd ? dim3(8, tx * ty, (F + 7) / 8) : dim3(tx, ty, F), 256, 0, st>>>(P, d_gray, stride, frame_stride, d_scaled, (int)F, xcd);
             PSL_STAGE_END(ctx, "line.lsd_scale");
         }
         {
@@ -184,19 +203,21 @@ struct pslfe_line {
             k_lsd_grad<<<dim3((P.W + 63) / 64, (P.H + PSL_GRAD_TH - 1) / PSL_GRAD_TH, F), 256, 0, st>>>(P, d_scaled, d_angdeg, d_modgrad, d_trig, d_seedt);
             PSL_STAGE_END(ctx, "line.lsd_grad");
         }
+        P.refine = refine;
         {
             PSL_STAGE_BEGIN(ctx, "line.lsd_grow");
-            const size_t lds = (((size_t)P.W * P.H + 31) / 32) * sizeof(uint32_t);
-            const char* variant = getenv("PSLFE_LSD_GROW");  // "serial" | "lds" | default: HBM bitmap, many waves per SIMD
-            if (!variant || (strcmp(variant, "serial") != 0 && strcmp(variant, "lds") != 0)) {
-                k_lsd_grow3<<<F, 64, 0, st>>>(P, d_angdeg, d_modgrad, d_trig, d_seedt, d_reg, d_seg, d_nseg);
-            } else if (lds <= 140 * 1024 && strcmp(variant, "lds") == 0) {
-                if (lds > 48 * 1024) PSL_HIP(hipFuncSetAttribute((const void*)k_lsd_grow2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                k_lsd_grow2<<<F, 64, lds, st>>>(P, d_angdeg, d_modgrad, d_trig, d_seedt, d_reg, d_seg, d_nseg);
-            } else {
-                k_lsd_grow<<<F, 64, 0, st>>>(P, d_angdeg, d_modgrad, d_used, d_reg, d_seg, d_nseg);
-            }
+            // LSD_REFINE_ADV: the kernel leaves rectangles (d_rects / d_nrect) for the NFA validation below
+            k_lsd_grow3<<<F, 64, 0, st>>>(P, d_angdeg, d_modgrad, d_trig, d_seedt, d_reg, d_seg, refine >= 2 ? d_nrect : d_nseg, d_rects);
             PSL_STAGE_END(ctx, "line.lsd_grow");
+        }
+        if (refine >= 2) {
+            PSL_STAGE_BEGIN(ctx, "line.lsd_nfa");
+            // a few hundred rectangles per frame: 64 workgroups x 4 waves cover a single frame in one or two passes, and a
+            // many-frames launch fills the chip by frames
+            const unsigned chunks = F >= 64 ? 16 : 64;
+            k_lsd_nfa<<<dim3(chunks, F), 256, 0, st>>>(P, d_angdeg, d_rects, d_nrect, d_segtmp, d_keep);
+            k_lsd_emit<<<F, 256, 0, st>>>(P, d_nrect, d_segtmp, d_keep, d_seg, d_nseg);
+            PSL_STAGE_END(ctx, "line.lsd_nfa");
         }
         PSL_HIP(hipGetLastError());
         last_nframes = nframes;
@@ -287,6 +308,13 @@ void pslfe_line_destroy(pslfe_line* line) {
     hipStreamSynchronize(line->ctx->stream);
     line->release();
     delete line;
+}
+
+int pslfe_line_set_refine(pslfe_line* line, int refine) {
+    PSL_REQUIRE(line, PSLFE_E_INVALID, "pslfe_line_set_refine: line is NULL");
+    PSL_REQUIRE(refine == PSLFE_LSD_REFINE_STD || refine == PSLFE_LSD_REFINE_ADV, PSLFE_E_INVALID, "pslfe_line_set_refine: mode %d", refine);
+    line->refine = refine;
+    return PSLFE_OK;
 }
 
 int pslfe_line_levels(const pslfe_line* line) { return line ? line->numOctaves : PSLFE_E_INVALID; }

@@ -96,13 +96,6 @@ struct pslfe_orb {
     uint8_t* d_in = nullptr;  // staging for the host-buffer entry points
     size_t in_fstride = 0;
     int in_pitch = 0;
-    bool fast_v1 = getenv("PSLFE_FAST_V1") != nullptr;        // A/B switch for the one-pixel-per-thread FAST kernel
-    // FAST(level 0) beside the pyramid on the second stream: +2.4 % frames/s at 256 frames (measured), off by default so that
-    // every stage runs alone and its event timing / roofline figure means what it says; PSLFE_OVERLAP=1 turns it on
-    bool no_overlap = getenv("PSLFE_OVERLAP") == nullptr;
-    bool no_xcd = getenv("PSLFE_NO_XCD") != nullptr;          // A/B switch for the XCD-aware grids
-    bool pyr_simple = getenv("PSLFE_PYR_SIMPLE") != nullptr;  // A/B switch for the untiled pyramid kernel
-
     int last_nframes = 0;
     FrameSrc last_src = {};
 
@@ -192,6 +185,18 @@ struct pslfe_orb {
 
         PSL_HIP(hipSetDevice(ctx->device));
         PSL_HIP(hipStreamSynchronize(ctx->stream));
+        // From here on buffers are freed and re-allocated one by one: forget the old geometry first, so that a failure below
+        // (dev_alloc returns early) cannot leave `w == gw && h == gh` true over freed or undersized buffers.
+        gw = gh = 0;
+        last_nframes = 0;
+        const int rc_alloc = allocate(Q, w, h, pyr_off, blur_off, cellcap);
+        if (rc_alloc) { release(); return rc_alloc; }
+        P = Q;
+        gw = w; gh = h;
+        return PSLFE_OK;
+    }
+
+    int allocate(const OrbParams& Q, int w, int h, size_t pyr_off, size_t blur_off, int cellcap) {
         const size_t F = (size_t)max_batch;
         pyr_fstride = psl_align_up(pyr_off, 256);
         blur_fstride = psl_align_up(blur_off, 256);
@@ -233,9 +238,6 @@ struct pslfe_orb {
             PSL_HIP(hipMemcpy(d_yofs[l], yo.data(), yo.size() * sizeof(int), hipMemcpyHostToDevice));
             PSL_HIP(hipMemcpy(d_beta[l], be.data(), be.size() * sizeof(short), hipMemcpyHostToDevice));
         }
-        P = Q;
-        gw = w; gh = h;
-        last_nframes = 0;
         return PSLFE_OK;
     }
 
@@ -247,44 +249,23 @@ struct pslfe_orb {
         FrameSrc S;
         S.img0 = d_gray; S.stride0 = stride; S.fstride0 = frame_stride; S.pyr = d_pyr; S.pyr_fstride = pyr_fstride;
         S.nframes = nframes;
-        S.xcd = (nframes >= 8 && !no_xcd) ? 1 : 0;
+        S.xcd = nframes >= 8 ? 1 : 0;
         const unsigned F = (unsigned)nframes;
         // grid over (items, frames): XCD-aware for many frames (orb_kernels.h: psl_item_frame)
         auto G = [&](unsigned items) { return S.xcd ? dim3(8, items, (F + 7) / 8) : dim3(items, F); };
-        // Level 0 is the caller's image: its FAST cells need no pyramid.  The pyramid is a chain of seven small, latency-
-        // bound launches that leave the vector units idle, FAST is bound by vector issue and its workgroups are short, so
-        // FAST(level 0) runs beside the pyramid on the context's second stream and FAST(levels >= 1) follows the pyramid.
-        const bool overlap = !no_overlap && nframes >= 8 && nlevels > 1 && !fast_v1;
-        const int cells0 = nlevels > 1 ? P.lv[1].cell_off : P.ncells;
-        if (overlap) {
-            PSL_HIP(hipEventRecord(ctx->ev_fork, st));
-            PSL_HIP(hipStreamWaitEvent(ctx->aux_stream, ctx->ev_fork, 0));
-            PSL_STAGE_BEGIN_ON(ctx, "orb.fast0", ctx->aux_stream);
-            k_fast_cells4<0><<<G(cells0), 256, 0, ctx->aux_stream>>>(P, S, d_celltab, d_cellcnt, d_cellcand, 0);
-            PSL_STAGE_END_ON(ctx, "orb.fast0", ctx->aux_stream);
-            PSL_HIP(hipEventRecord(ctx->ev_join, ctx->aux_stream));
-        }
         {
             PSL_STAGE_BEGIN(ctx, "orb.pyramid");
             for (int l = 1; l < nlevels; ++l) {
-                if (pyr_simple) {
-                    dim3 grid((P.lv[l].pitch / 4 + 63) / 64, (P.lv[l].h + 3) / 4, F);
-                    k_pyr_resize<<<grid, 256, 0, st>>>(P, S, l, d_xofs[l], d_alpha[l], d_yofs[l], d_beta[l]);
-                } else {
-                    const unsigned nb = (unsigned)(((P.lv[l].pitch + 63) / 64) * ((P.lv[l].h + PSL_PYR_BH - 1) / PSL_PYR_BH));
-                    k_pyr_resize_tiled<<<G(nb), 256, 0, st>>>(P, S, l, d_xofs[l], d_alpha[l], d_yofs[l], d_beta[l]);
-                }
+                const unsigned nb = (unsigned)(((P.lv[l].pitch + 63) / 64) * ((P.lv[l].h + PSL_PYR_BH - 1) / PSL_PYR_BH));
+                k_pyr_resize_tiled<<<G(nb), 256, 0, st>>>(P, S, l, d_xofs[l], d_alpha[l], d_yofs[l], d_beta[l]);
             }
             PSL_STAGE_END(ctx, "orb.pyramid");
         }
         {
             PSL_STAGE_BEGIN(ctx, "orb.fast");
-            if (fast_v1) k_fast_cells<<<dim3(P.ncells, F), 256, 0, st>>>(P, S, d_cellcnt, d_cellcand);
-            else if (overlap) k_fast_cells4<1><<<G(P.ncells - cells0), 256, 0, st>>>(P, S, d_celltab, d_cellcnt, d_cellcand, cells0);
-            else k_fast_cells4<1><<<G(P.ncells), 256, 0, st>>>(P, S, d_celltab, d_cellcnt, d_cellcand, 0);
+            k_fast_cells4<<<G(P.ncells), 256, 0, st>>>(P, S, d_celltab, d_cellcnt, d_cellcand, 0);
             PSL_STAGE_END(ctx, "orb.fast");
         }
-        if (overlap) PSL_HIP(hipStreamWaitEvent(st, ctx->ev_join, 0));
         {
             PSL_STAGE_BEGIN(ctx, "orb.octree");
             if (oct_bs == 256)

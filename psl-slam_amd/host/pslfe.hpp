@@ -211,6 +211,8 @@ public:
         check(pslfe_lil_pair(h_, mLines.data(), n, radius, fanThr, imgCols, imgRows, fans.data(), cap, &k), "pslfe_lil_pair");
         fans.resize((size_t)k * 4);
     }
+    // PSLFE_LSD_REFINE_ADV (default, what the stock contrib LSDDetector constructs) or PSLFE_LSD_REFINE_STD
+    void SetRefine(int mode) { check(pslfe_line_set_refine(h_, mode), "pslfe_line_set_refine"); }
     int GetLevels() const { return pslfe_line_levels(h_); }
     float GetScaleFactor() const { return pslfe_line_scale_factor(h_); }
     std::vector<float> GetScaleFactors() const { return factors(0); }

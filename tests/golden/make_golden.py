@@ -56,10 +56,13 @@ def main():
 def lines():
     img = sf.Scene(640, 480, "struct", sf.SEED + 1).gray(2)
     kls, desc, eq = oracle_lib.line_extract(img, 200)
-    seg = oracle_lib.lsd_detect(img)
+    seg = oracle_lib.lsd_detect(img)            # LSD_REFINE_ADV, the default
+    oracle_lib.set_lsd_refine(1)
+    seg_std = oracle_lib.lsd_detect(img)        # LSD_REFINE_STD
+    oracle_lib.set_lsd_refine(2)
     L = np.stack([kls[n] for n in ("startPointX", "startPointY", "endPointX", "endPointY")], 1).astype(np.float32)
     fans = oracle_lib.lil_pair(L, 20.0, np.float32(np.pi / 4), 640, 480)
-    np.savez_compressed(os.path.join(HERE, "line_640x480_struct.npz"), image=img, segments=seg, kls=kls, desc=desc, eq=eq, fans=fans)
+    np.savez_compressed(os.path.join(HERE, "line_640x480_struct.npz"), image=img, segments=seg, segments_std=seg_std, kls=kls, desc=desc, eq=eq, fans=fans)
     print("lines", len(seg), len(kls), len(fans))
 
 

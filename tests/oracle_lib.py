@@ -540,3 +540,36 @@ def distinctive_descriptors(desc, offsets):
     L.pso_distinctive_descriptors.restype = None
     L.pso_distinctive_descriptors(_p(desc), _p(off), len(off) - 1, _p(best))
     return best[:len(off) - 1]
+
+
+def set_lsd_refine(mode):
+    """1 = LSD_REFINE_STD, 2 = LSD_REFINE_ADV (the oracle's default); returns the previous mode."""
+    L = load()
+    return L.pso_set_lsd_refine(int(mode))
+
+
+def set_nfa_math(restated):
+    """0 = host libm in nfa() (default), 1 = the product's restated log / exp / log10 (psl_f64math.h)."""
+    L = load()
+    return L.pso_set_nfa_math(int(restated))
+
+
+def lsd_nfa(n, k, p, W, H):
+    L = load()
+    L.pso_lsd_nfa.restype = C.c_double
+    L.pso_lsd_nfa.argtypes = [C.c_int, C.c_int, C.c_double, C.c_int, C.c_int]
+    return L.pso_lsd_nfa(n, k, p, W, H)
+
+
+LSD_RECT_FIELDS = ("x1", "y1", "x2", "y2", "width", "x", "y", "theta", "dx", "dy", "prec", "p")
+
+
+def lsd_rects(img, cap=20000):
+    """The rectangles LSD hands to rect_improve (LSD_REFINE_ADV), in seed order: (n, 12) float64."""
+    L = load()
+    img = np.ascontiguousarray(img)
+    h, w = img.shape
+    r = np.zeros((cap, 12), np.float64)
+    L.pso_lsd_rects.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
+    n = L.pso_lsd_rects(_p(img), w, h, img.strides[0], _p(r), cap)
+    return r[:n].copy()

@@ -1,10 +1,10 @@
-"""GPU parity of the line front-end vs the CPU oracle (oracle/line_oracle.cpp).
-
-Stages that are pure IEEE arithmetic in a fixed order (LSD working image, gradient norm, level-line
-angle, LBD given keylines, merge, pairing) are compared exactly.  LSD segments depend on double
-cos/sin from libm (host) vs the device math library inside a serial chain; the stated tolerance
- is: >= 95 % of oracle segments recovered with endpoints within 0.5 px — in practice the
-lists are identical and the test reports it.
+"""GPU parity of the line front-end vs the CPU oracle (oracle/line_oracle.cpp): every stage and the whole extractor are
+compared BIT FOR BIT (segments, keylines, LBD descriptors, line equations, fans), in both LSD refinement modes
+(LSD_REFINE_ADV = default, LSD_REFINE_STD).  The device calls no math library on this path: sinf / cosf / atanf / atan2f / tanf
+are glibc's float algorithms restated and pinned exhaustively against libm in the CPU suite; the double-precision functions
+whose glibc form cannot be reproduced offline (sin / cos of MergeTwoLines, log / exp / log10 of the NFA) are fdlibm's, within
+1-2 ulp of glibc (tests/test_f64math_cpu.py) - a difference that can reach an output only on an exact rounding tie; none
+occurs on any frame compared here.
 """
 import numpy as np
 import pytest
@@ -16,8 +16,28 @@ pytestmark = pytest.mark.gpu
 DEG2RAD = np.pi / 180
 
 
+ADV, STD = 2, 1
+
+
 def _scene(style, seed, t=0, w=640, h=480):
     return sf.Scene(w, h, style, seed).gray(t)
+
+
+@pytest.fixture
+def refine_mode(request):
+    """Sets the oracle's LSD refinement mode for one test and restores the default (ADV) afterwards."""
+    import oracle_lib
+    mode = getattr(request, "param", ADV)
+    oracle_lib.set_lsd_refine(mode)
+    yield mode
+    oracle_lib.set_lsd_refine(ADV)
+
+
+def _extractor(mode, *a, **kw):
+    import psl_slam_amd as P
+    le = P.LINEextractor(*a, **kw)
+    le.set_refine(mode)
+    return le
 
 
 @pytest.mark.parametrize("style,seed", [("struct", 3), ("desk", 4)])
@@ -45,18 +65,17 @@ def _match_segments(got, ref, tol=0.5):
     return hit / len(ref)
 
 
+@pytest.mark.parametrize("refine_mode", [ADV, STD], indirect=True)
 @pytest.mark.parametrize("style,seed", [("struct", 3), ("desk", 4), ("struct", 8)])
-def test_lsd_segments(style, seed):
-    import psl_slam_amd as P
+def test_lsd_segments(style, seed, refine_mode):
     import oracle_lib
     img = _scene(style, seed)
-    got = P.LINEextractor().lsd_detect(img)
+    got = _extractor(refine_mode).lsd_detect(img)
     ref = oracle_lib.lsd_detect(img)
-    frac = _match_segments(got, ref)
     exact = got.shape == ref.shape and (got.view(np.uint32) == ref.view(np.uint32)).all()
-    print(f"LSD {style}/{seed}: {len(got)} vs oracle {len(ref)} segments, recovered {frac:.4f}, bit-identical {exact}")
-    assert len(ref) > 100
-    assert frac >= 0.95 and abs(len(got) - len(ref)) <= 0.05 * len(ref)
+    print(f"LSD {style}/{seed} refine {refine_mode}: {len(got)} vs oracle {len(ref)} segments, recovered {_match_segments(got, ref):.4f}, bit-identical {exact}")
+    assert len(ref) > (100 if refine_mode == STD else 40)
+    assert exact
 
 
 def test_lsd_large_regions_exercise_queue_overflow():
@@ -71,12 +90,16 @@ def test_lsd_large_regions_exercise_queue_overflow():
     img[180:190, 340:620] = 240
     rng = np.random.default_rng(5)
     img = np.clip(img + rng.normal(0, 1.0, img.shape), 0, 255).astype(np.uint8)
-    got = P.LINEextractor().lsd_detect(img)
-    ref = oracle_lib.lsd_detect(img)
-    exact = got.shape == ref.shape and (got.view(np.uint32) == ref.view(np.uint32)).all()
-    print(f"LSD ramps: {len(got)} vs oracle {len(ref)} segments, bit-identical {exact}")
-    assert len(ref) >= 4 and _match_segments(got, ref) >= 0.95 and abs(len(got) - len(ref)) <= max(1, 0.05 * len(ref))
-    assert exact
+    for mode in (ADV, STD):
+        oracle_lib.set_lsd_refine(mode)
+        try:
+            ref = oracle_lib.lsd_detect(img)
+        finally:
+            oracle_lib.set_lsd_refine(ADV)
+        got = _extractor(mode).lsd_detect(img)
+        exact = got.shape == ref.shape and (got.view(np.uint32) == ref.view(np.uint32)).all()
+        print(f"LSD ramps refine {mode}: {len(got)} vs oracle {len(ref)} segments, bit-identical {exact}")
+        assert len(ref) >= (4 if mode == STD else 2) and exact
 
 
 def test_lsd_flat_image_gives_no_segments():
@@ -96,24 +119,21 @@ def _kl_equal(a, b, what, skip=()):
 
 @pytest.mark.parametrize("style,seed", [("struct", 3), ("desk", 4), ("struct", 8)])
 def test_merge_stage_on_oracle_segments(style, seed):
-    """optimizeAndMergeLines_lsd on identical input segments.  atanf / atan2f are glibc's algorithms restated (pinned against
-    libm in the CPU suite); the double sin, cos of MergeTwoLines come from the device math library vs glibc in the oracle
-    (last-ulp differences possible), so the contract is a tolerance: same number of lines, endpoints within 0.01 px; bit-identity is
-    reported."""
+    """optimizeAndMergeLines_lsd on identical input segments (the STD segment list: more lines, more merges): every KeyLine field
+    bit-identical.  atanf / atan2f are glibc's algorithms restated; the double sin / cos of MergeTwoLines are fdlibm's (header)."""
     import psl_slam_amd as P
     import oracle_lib
     img = _scene(style, seed)
-    seg = oracle_lib.lsd_detect(img)
+    oracle_lib.set_lsd_refine(STD)
+    try:
+        seg = oracle_lib.lsd_detect(img)
+    finally:
+        oracle_lib.set_lsd_refine(ADV)
     ref = oracle_lib.optimize_and_merge(seg, 640, 480)
     got = P.LINEextractor().optimize_and_merge(seg, 640, 480)
-    assert len(got) == len(ref) and len(ref) > 10
-    ge = np.stack([got[n] for n in ("startPointX", "startPointY", "endPointX", "endPointY")], 1)
-    re_ = np.stack([ref[n] for n in ("startPointX", "startPointY", "endPointX", "endPointY")], 1)
-    assert np.abs(ge - re_).max() <= 0.01
-    np.testing.assert_array_equal(got["numOfPixels"], ref["numOfPixels"])
-    np.testing.assert_array_equal(got["class_id"], ref["class_id"])
-    exact = got.tobytes() == ref.tobytes()
-    print(f"merge {style}/{seed}: {len(seg)} segments -> {len(got)} keylines, bit-identical {exact}")
+    assert len(ref) > 10
+    _kl_equal(got, ref, f"merge {style}/{seed}")
+    print(f"merge {style}/{seed}: {len(seg)} segments -> {len(got)} keylines, bit-identical")
 
 
 @pytest.mark.parametrize("style,seed", [("struct", 3), ("desk", 4)])
@@ -165,38 +185,34 @@ def test_pairing_on_oracle_lines(style, seed):
     lines = np.stack([kls[n] for n in ("startPointX", "startPointY", "endPointX", "endPointY")], 1).astype(np.float32)
     ref = oracle_lib.lil_pair(lines, 20.0, np.float32(np.pi / 4), 640, 480)
     got = P.LINEextractor().pair(lines, 20.0, np.float32(np.pi / 4), 640, 480)
-    assert got.shape == ref.shape and len(ref) > 5
-    np.testing.assert_array_equal(got[:, 2:], ref[:, 2:])
-    assert np.abs(got[:, :2] - ref[:, :2]).max() <= 1e-3
-    print(f"pairing {style}/{seed}: {len(ref)} fans, bit-identical {got.tobytes() == ref.tobytes()}")
+    assert got.shape == ref.shape and len(ref) > 3
+    np.testing.assert_array_equal(got.view(np.uint32), ref.view(np.uint32))
     # degenerate inputs: no lines, one line
     assert len(P.LINEextractor().pair(np.zeros((0, 4), np.float32), 20.0, 0.785, 640, 480)) == 0
     assert len(P.LINEextractor().pair(lines[:1], 20.0, 0.785, 640, 480)) == 0
 
 
-@pytest.mark.parametrize("style,seed", [("struct", 3), ("desk", 4), ("struct", 8)])
-def test_full_line_extractor(style, seed):
-    """LINEextractor::operator(): tolerance contract (SURVEY.md H8): >= 95 % of the oracle's keylines
-    recovered with endpoints within 0.5 px and, on the recovered ones, LBD Hamming distance <= 8."""
-    import psl_slam_amd as P
+def _assert_extract_equal(got, ref, what):
+    gk, gd, ge = got
+    rk, rd, re_ = ref
+    _kl_equal(gk, rk, what)
+    np.testing.assert_array_equal(gd, rd, err_msg=what)
+    np.testing.assert_array_equal(ge.view(np.uint64), re_.view(np.uint64), err_msg=what)
+
+
+@pytest.mark.parametrize("refine_mode", [ADV, STD], indirect=True)
+@pytest.mark.parametrize("style,seed,t", [("struct", 3, 0), ("desk", 4, 0), ("struct", 8, 0), ("struct", 5, 0), ("desk", 7, 7), ("struct", 9, 15),
+                                          ("desk", 11, 23)])
+def test_full_line_extractor(style, seed, t, refine_mode):
+    """LINEextractor::operator() bit for bit: keylines (all 17 fields), LBD descriptors, line equations.  struct/5 t=0 is the
+    frame of round 1's stress-run mismatch (one LBD row, |dx| 1.2e-4, before atanf was restated); the last three are frames of
+    that stress set."""
     import oracle_lib
-    img = _scene(style, seed)
-    rk, rd, re_ = oracle_lib.line_extract(img, 200)
-    gk, gd, ge = P.LINEextractor(1, 1.2, 200, 0.0)(img)
-    assert len(rk) > 20 and abs(len(gk) - len(rk)) <= 0.05 * len(rk)
-    R = np.stack([rk[n] for n in ("startPointX", "startPointY", "endPointX", "endPointY")], 1)
-    G = np.stack([gk[n] for n in ("startPointX", "startPointY", "endPointX", "endPointY")], 1)
-    hit = 0
-    for i, r in enumerate(R):
-        d = np.abs(G - r).max(1)
-        j = int(d.argmin())
-        if d[j] <= 0.5:
-            hit += 1
-            assert int(np.unpackbits(gd[j] ^ rd[i]).sum()) <= 8
-            assert np.abs(ge[j] - re_[i]).max() <= 1e-2 * max(1.0, np.abs(re_[i]).max())
-    exact = gk.tobytes() == rk.tobytes() and (gd == rd).all() and ge.tobytes() == re_.tobytes()
-    print(f"line extract {style}/{seed}: {len(gk)} vs {len(rk)} keylines, recovered {hit / len(rk):.4f}, bit-identical {exact}")
-    assert hit >= 0.95 * len(rk)
+    img = _scene(style, seed, t)
+    ref = oracle_lib.line_extract(img, 200)
+    got = _extractor(refine_mode, 1, 1.2, 200, 0.0)(img)
+    assert len(ref[0]) > (20 if refine_mode == STD else 8)
+    _assert_extract_equal(got, ref, f"line extract {style}/{seed}/{t} refine {refine_mode}")
 
 
 def test_line_extractor_batch_and_pairing_device():
@@ -248,8 +264,8 @@ def test_line_extractor_empty_inputs():
 
 
 def test_hip_vs_committed_line_golden():
-    """HIP vs tests/golden/line_640x480_struct.npz: LSD segments, LBD on the golden keylines and pairing on the
-    golden lines are exact; the end-to-end extractor stays within the stated tolerance."""
+    """HIP vs tests/golden/line_640x480_struct.npz, everything exact: LSD segments (both refinement modes), LBD on the golden
+    keylines, pairing on the golden lines and the end-to-end extractor."""
     import os
     import psl_slam_amd as P
     g = np.load(os.path.join(os.path.dirname(__file__), "golden", "line_640x480_struct.npz"))
@@ -260,10 +276,9 @@ def test_hip_vs_committed_line_golden():
     L = np.stack([g["kls"][n] for n in ("startPointX", "startPointY", "endPointX", "endPointY")], 1).astype(np.float32)
     np.testing.assert_array_equal(le.pair(L, 20.0, np.float32(np.pi / 4), 640, 480), g["fans"])
     k, d, e = le(g["image"])
-    assert len(k) == len(g["kls"])
-    E = np.stack([k[n] for n in ("startPointX", "startPointY", "endPointX", "endPointY")], 1)
-    R = np.stack([g["kls"][n] for n in ("startPointX", "startPointY", "endPointX", "endPointY")], 1)
-    assert np.abs(E - R).max() <= 0.5
+    assert k.tobytes() == g["kls"].tobytes() and (d == g["desc"]).all() and e.tobytes() == g["eq"].tobytes()
+    le.set_refine(STD)
+    np.testing.assert_array_equal(le.lsd_detect(g["image"]).view(np.uint32), g["segments_std"].view(np.uint32))
 
 
 def test_line_extractor_xcd_grid_ragged_batch():
@@ -285,28 +300,29 @@ def test_line_extractor_xcd_grid_ragged_batch():
 @pytest.mark.parametrize("nscenes", [2, 4])
 def test_merge_stage_more_segments_than_the_small_lds_instance(nscenes):
     """k_line_merge exists for 512 and 1024 lines in LDS, beyond that its working set is in HBM: segment lists of ~700 and
-    ~1400 lines (several scenes' segments in one list) exercise the other two paths; same contract as above."""
+    ~1400 lines (several scenes' STD segments in one list) exercise the other two paths; bit-identical as above."""
     import psl_slam_amd as P
     import oracle_lib
-    seg = np.concatenate([oracle_lib.lsd_detect(_scene(st, sd)) for st, sd in (("desk", 4), ("struct", 3), ("desk", 9), ("desk", 12))[:nscenes]])
+    oracle_lib.set_lsd_refine(STD)
+    try:
+        seg = np.concatenate([oracle_lib.lsd_detect(_scene(st, sd)) for st, sd in (("desk", 4), ("struct", 3), ("desk", 9), ("desk", 12))[:nscenes]])
+    finally:
+        oracle_lib.set_lsd_refine(ADV)
     assert len(seg) > (512 if nscenes == 2 else 1024)
     ref = oracle_lib.optimize_and_merge(seg, 640, 480, cap=4096)
     got = P.LINEextractor().optimize_and_merge(seg, 640, 480, cap=4096)
-    assert len(got) == len(ref) and len(ref) > 100
-    ge = np.stack([got[n] for n in ("startPointX", "startPointY", "endPointX", "endPointY")], 1)
-    re_ = np.stack([ref[n] for n in ("startPointX", "startPointY", "endPointX", "endPointY")], 1)
-    assert np.abs(ge - re_).max() <= 0.01
-    np.testing.assert_array_equal(got["numOfPixels"], ref["numOfPixels"])
-    print(f"merge of {len(seg)} segments -> {len(got)} keylines, bit-identical {got.tobytes() == ref.tobytes()}")
+    assert len(ref) > 100
+    _kl_equal(got, ref, f"merge of {len(seg)} segments")
 
 
-def test_lsd_segments_bit_identical_over_many_frames():
+@pytest.mark.parametrize("refine_mode", [ADV, STD], indirect=True)
+def test_lsd_segments_bit_identical_over_many_frames(refine_mode):
     """The region growing decides most neighbours against an angle that is NOT up to date (a rigorous bound on its drift
-    replaces the per-pixel fastAtan2, line_kernels.h): every shortcut must give the reference's decision, so the segment
-    lists of many different frames are compared bit for bit (textured and structure-like scenes, several time steps)."""
-    import psl_slam_amd as P
+    replaces the per-pixel fastAtan2, line_kernels.h), and the NFA validation runs as its own kernel with restated log / exp
+    (line_kernels3.h): every shortcut must give the reference's decision, so the segment lists of many different frames are
+    compared bit for bit (textured and structure-like scenes, several time steps)."""
     import oracle_lib
-    le = P.LINEextractor()
+    le = _extractor(refine_mode)
     nseg = 0
     for style, seed in (("desk", 31), ("struct", 32), ("desk", 33), ("struct", 34)):
         sc = sf.Scene(640, 480, style, seed)
@@ -316,4 +332,42 @@ def test_lsd_segments_bit_identical_over_many_frames():
             ref = oracle_lib.lsd_detect(img)
             assert got.shape == ref.shape and (got.view(np.uint32) == ref.view(np.uint32)).all(), (style, seed, t)
             nseg += len(ref)
-    assert nseg > 5000
+    assert nseg > (5000 if refine_mode == STD else 2000)
+
+
+def test_full_size_line_batch_properties():
+    """768 frames in one launch (6 LSD waves per SIMD on 128 CUs' worth of workgroups, XCD-aware grids, both merge instances):
+    96 distinct frames x 8; twins of a frame are byte-identical, a second run of the batch is byte-identical, and 16 sampled
+    frames equal the CPU oracle bit for bit (keylines, descriptors, line equations, fans)."""
+    import zlib
+    import oracle_lib
+    import psl_slam_amd as P
+    frames = []
+    for style, seed in (("struct", 5), ("desk", 7), ("struct", 9), ("desk", 11)):
+        sc = sf.Scene(640, 480, style, seed)
+        frames += [sc.gray(t) for t in range(24)]
+    frames = np.stack(frames, 0)
+    n = 768
+    batch = np.ascontiguousarray(np.concatenate([frames] * (n // len(frames)), 0))
+    le = P.LINEextractor(1, 1.2, 200, 0.0, max_batch=n)
+    d_ptr, _ = le.ctx.device_array(batch)
+    crcs = []
+    for rep in range(2):
+        le.extract_batch_device(d_ptr, n, 640, 480, 640, 640 * 480)
+        le.pair_batch_device(20.0, np.float32(np.pi / 4))
+        per = []
+        for f in range(n):
+            k, dsc, eq, st = le.fetch(f)
+            assert st == 0
+            per.append(zlib.crc32(k.tobytes()) ^ zlib.crc32(dsc.tobytes()) ^ zlib.crc32(eq.tobytes()) ^ zlib.crc32(le.fans_fetch(f).tobytes()))
+        crcs.append(per)
+    assert crcs[0] == crcs[1], "a second run of the same batch differs"
+    for f in range(len(frames), n):
+        assert crcs[0][f] == crcs[0][f % len(frames)], f"frame {f} differs from its twin {f % len(frames)}"
+    for f in np.linspace(0, n - 1, 16).astype(int):
+        f = int(f)
+        k, dsc, eq, _ = le.fetch(f)
+        _assert_extract_equal((k, dsc, eq), oracle_lib.line_extract(batch[f], 200), f"batch frame {f}")
+        L = np.stack([k[m] for m in ("startPointX", "startPointY", "endPointX", "endPointY")], 1).astype(np.float32)
+        np.testing.assert_array_equal(le.fans_fetch(f).view(np.uint32), oracle_lib.lil_pair(L, 20.0, np.float32(np.pi / 4), 640, 480).view(np.uint32))
+    le.ctx.device_free(d_ptr)

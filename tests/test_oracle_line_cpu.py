@@ -91,7 +91,13 @@ def test_line_golden_vectors():
     assert kls.tobytes() == g["kls"].tobytes()
     np.testing.assert_array_equal(desc, g["desc"])
     np.testing.assert_array_equal(eq, g["eq"])
-    np.testing.assert_array_equal(oracle_lib.lsd_detect(g["image"]), g["segments"])
+    np.testing.assert_array_equal(oracle_lib.lsd_detect(g["image"]), g["segments"])          # LSD_REFINE_ADV (default)
+    oracle_lib.set_lsd_refine(1)
+    try:
+        np.testing.assert_array_equal(oracle_lib.lsd_detect(g["image"]), g["segments_std"])  # LSD_REFINE_STD
+    finally:
+        oracle_lib.set_lsd_refine(2)
+    assert 0 < len(g["segments"]) < len(g["segments_std"])
     L = np.stack([kls[n] for n in ("startPointX", "startPointY", "endPointX", "endPointY")], 1).astype(np.float32)
     np.testing.assert_array_equal(oracle_lib.lil_pair(L, 20.0, np.float32(np.pi / 4), 640, 480), g["fans"])
 
