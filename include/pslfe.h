@@ -529,6 +529,59 @@ int pslfe_glue_fetch(pslfe_glue* g, int frame, int nlines, double* lines3d, floa
                      double* cross, double* le_l, int int_cap, int* nint, float* planes, double* normals, int32_t* lineNo,
                      double* cross3d, double* cross2d, int plane_cap, int* nplanes);
 
+/* ---- batched many-frames mode across the GPUs of one node (BASELINE configs[3]) -----------------------
+ * The reference has no counterpart (it is single-process, single-camera: src/System.cc:91-101); north_star asks for
+ * independent frames / streams sharded over the 8 GPUs with RCCL over xGMI for the result gather.  Stream s -> rank
+ * s mod world, no data-path collective; the one exchange is an all-gather of fixed-size per-frame RESULT RECORDS holding
+ * what Tracking.cc reads of a Frame on this path.  Record (little endian, sections 16-byte aligned, zero padded):
+ *   header  8 x int32: n_kp, n_match, n_kl, n_lmatch, n_fan, n_planes (true counts), flags (bit0 kps / bit1 lines / bit2 fans /
+ *           bit3 planes truncated to the capacity), frame index inside the rank's batch
+ *   kps     [kp_cap] PslKeyPoint    = mvKeys               desc   [kp_cap][32] = mDescriptors
+ *   match   [kp_cap] int32          = ORBmatcher::SearchByProjection result (query i -> keypoint of this frame, -1 none; all kp_cap rows of the
+ *                                     caller's buffer, which holds -1 beyond the query count)
+ *   kls     [kl_cap] PslKeyLine     = mvKeylinesUn         ldesc  [kl_cap][32] = mLdesc
+ *   lineEq  [kl_cap][3] f64         = mvKeyLineFunctions   lmatch [kl_cap] int32 = LSDmatcher::match result
+ *   fans    [fan_cap][4] f32        = CPartiallyRecoverConnectivity rows (x, y, i, j)
+ *   planes  [plane_cap][4] f32      = mvPlanes             plane_lines [plane_cap][2] int32 = mvPlaneLineNo          */
+typedef struct PslRecordCaps { int32_t kp_cap, kl_cap, fan_cap, plane_cap; } PslRecordCaps;
+typedef struct PslRecordLayout {
+    int64_t bytes;  /* size of one record, a multiple of 256 */
+    int64_t off_kps, off_desc, off_match, off_kls, off_ldesc, off_lineEq, off_lmatch, off_fans, off_planes, off_plane_lines;
+} PslRecordLayout;
+/* Pure host arithmetic (no GPU needed): the offsets every consumer of a record uses. */
+int pslfe_record_layout(const PslRecordCaps* caps, PslRecordLayout* out);
+/* Where the results of a batch live in HBM (the *_results_device / *_fans_device views and the caller's match buffers);
+ * a NULL pointer leaves its section empty.  Strides are in rows per frame. */
+typedef struct PslRecordSources {
+    const PslKeyPoint* d_kps; const uint8_t* d_desc; const int32_t* d_kp_counts; int32_t kp_stride;
+    const int32_t* d_match; const int32_t* d_nmatches; int32_t match_stride;
+    const PslKeyLine* d_kls; const uint8_t* d_ldesc; const double* d_lineEq; const int32_t* d_kl_counts; int32_t kl_stride;
+    const int32_t* d_lmatch; const int32_t* d_nlmatches; int32_t lmatch_stride;
+    const float* d_fans; const int32_t* d_fan_counts; int32_t fan_stride;
+    const float* d_planes; const int32_t* d_plane_lines; const int32_t* d_plane_counts; int32_t plane_stride;
+} PslRecordSources;
+/* Packs the records of nframes frames into d_records ([nframes][layout.bytes]), asynchronously on the context's stream. */
+int pslfe_record_pack_device(pslfe_ctx* ctx, const PslRecordCaps* caps, const PslRecordSources* src, int nframes, void* d_records);
+/* mvPlanes / mvPlaneLineNo / their counts of the last pslfe_glue_run_batch_device, HBM resident ([nframes][plane_stride][..]). */
+int pslfe_glue_planes_device(pslfe_glue* g, const float** d_planes, const int32_t** d_plane_lines, const int32_t** d_plane_counts,
+                             int* plane_stride);
+
+/* RCCL all-gather of the records, one communicator per context.  RCCL is loaded at run time (librccl.so.1).
+ *   pslfe_gather_unique_id  rank 0 obtains the 128-byte ncclUniqueId and hands it to the other ranks by whatever channel the
+ *                           host has (MPI, a socket, torch.distributed, a file);
+ *   pslfe_gather_create     ncclCommInitRank - collective: every rank calls it with the same id;
+ *   pslfe_gather_all        d_recv[world][bytes_per_rank] <- every rank's d_send[bytes_per_rank]; runs on the gather's own
+ *                           stream AFTER everything issued on the context's stream so far, so the next batch's kernels
+ *                           overlap it; one exchange may be in flight;
+ *   pslfe_gather_wait       host_blocking != 0: the host waits for the exchange; 0: the context's stream waits for it. */
+typedef struct pslfe_gather pslfe_gather;
+int pslfe_gather_unique_id(uint8_t id[128]);
+int pslfe_gather_create(pslfe_ctx* ctx, int rank, int world, const uint8_t id[128], pslfe_gather** out);
+void pslfe_gather_destroy(pslfe_gather* g);
+int pslfe_gather_all(pslfe_gather* g, const void* d_send, size_t bytes_per_rank, void* d_recv);
+int pslfe_gather_wait(pslfe_gather* g, int host_blocking);
+int pslfe_gather_world(const pslfe_gather* g, int* rank, int* world);
+
 #ifdef __cplusplus
 }
 #endif

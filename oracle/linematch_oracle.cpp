@@ -91,6 +91,17 @@ int hamming(const uint8_t* a, const uint8_t* b) { return pso_hamming256(a, b); }
 
 extern "C" {
 
+// the Bresenham walk alone (tap for tests/test_oracle_ref_cpu.py, which compares it with the reference's own lineIterator.cpp)
+int pso_line_iterator_walk(double x1, double y1, double x2, double y2, int* xy, int cap) {
+    LineIt it(x1, y1, x2, y2);
+    int px, py, n = 0;
+    while (it.next(px, py)) {
+        if (n < cap) { xy[2 * n] = px; xy[2 * n + 1] = py; }
+        ++n;
+    }
+    return n;
+}
+
 // CSR of mGridForLine, cell = ix*48+iy; idx capacity >= sum over lines of visited cells
 int pso_line_grid_build(const PsoKeyLine* k, int n, float minX, float minY, float maxX, float maxY, int* start, int* idx, int cap) {
     LGrid* g = new LGrid();

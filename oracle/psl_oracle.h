@@ -109,6 +109,7 @@ int pso_lsd_gradient(const uint8_t* gray, int w, int h, int stride, double* scal
 int pso_merge_lines(const float* src, int n, float ang, float dist, float ep, float* dst, int cap);
 int pso_optimize_and_merge(const float* src, int n, int w, int h, PsoKeyLine* out, int cap);
 int pso_line_iterator_count(int w, int h, float x1, float y1, float x2, float y2);
+int pso_line_iterator_walk(double x1, double y1, double x2, double y2, int* xy, int cap);
 int pso_lbd_compute(const uint8_t* gray, int w, int h, int stride, const PsoKeyLine* kls, int n, uint8_t* desc, float* fdesc);
 int pso_lbd_sobel(const uint8_t* gray, int w, int h, int stride, short* dx, short* dy);
 int pso_line_extract(const uint8_t* gray, int w, int h, int stride, int nLSDFeature, PsoKeyLine* kls, uint8_t* desc,

@@ -796,4 +796,14 @@ int pslfe_glue_fetch(pslfe_glue* g, int frame, int nlines, double* lines3d, floa
     return PSLFE_OK;
 }
 
+int pslfe_glue_planes_device(pslfe_glue* g, const float** d_planes, const int32_t** d_plane_lines, const int32_t** d_plane_counts, int* plane_stride) {
+    PSL_REQUIRE(g, PSLFE_E_INVALID, "pslfe_glue_planes_device: glue is NULL");
+    PSL_REQUIRE(g->last_nframes > 0, PSLFE_E_STATE, "pslfe_glue_planes_device: no batch processed yet");
+    if (d_planes) *d_planes = g->d_planes;
+    if (d_plane_lines) *d_plane_lines = g->d_lineNo;
+    if (d_plane_counts) *d_plane_counts = g->d_nplanes;
+    if (plane_stride) *plane_stride = g->plane_cap;
+    return PSLFE_OK;
+}
+
 }  // extern "C"

@@ -69,3 +69,102 @@ def read_results(path, nframes):
                 d[name] = np.fromfile(f, dt, n)
             out.append(d)
     return out
+
+
+def camera(w):
+    """The camera dropin_main builds: Examples/RGB-D/TUM3.yaml scaled with the image width, zero distortion (f32 arithmetic)."""
+    import psl_slam_amd as P
+    s = np.float32(w) / np.float32(640.0)
+    cam = np.zeros((), P.CAMERA_DTYPE)
+    for k, v in zip(("fx", "fy", "cx", "cy"), (535.4, 539.2, 320.1, 247.6)):
+        cam[k] = np.float32(v) * s
+    cam["bf"] = np.float32(40.0) * s
+    return cam
+
+
+def oracle_sequence(gray, depth, nfeatures, nlines, stage_ms=None, first=0, lines=True, frame_ms=None):
+    """The same Frame::Frame + TrackWithMotionModel call sequence as tools/dropin/dropin_main.cpp, on the CPU oracle
+    (tests/oracle_lib.py).  Returns one dict per frame with the arrays read_results() yields; stage_ms (a dict) accumulates the
+    wall time of every call, so this is also the per-stage CPU baseline of the drop-in workloads."""
+    import time
+    import oracle_lib as O
+    n, h, w = gray.shape
+    cam = camera(w)
+    orb = O.OracleORB(nfeatures, 1.2, 8, 20, 7)
+    scale = np.cumprod(np.concatenate([[np.float32(1.0)], np.full(7, 1.2, np.float64)])).astype(np.float32)
+    b = O.image_bounds(cam, w, h)  # mnMinX, mnMinY, mnMaxX, mnMaxY
+    bounds = tuple(float(x) for x in b)
+    out, last = [], None
+
+    def lap(name, t0):
+        if stage_ms is not None:
+            stage_ms[name] = stage_ms.get(name, 0.0) + (time.perf_counter() - t0) * 1e3
+        return time.perf_counter()
+
+    empty_kl = (np.zeros(0, O.KEYLINE_DTYPE), np.zeros((0, 32), np.uint8), np.zeros((0, 3)))
+    for t in range(n):
+        t0 = tf = time.perf_counter()
+        cur = {}
+        cur["mvKeys"], cur["mDescriptors"] = orb(gray[t])
+        t0 = lap("ORBextractor()", t0)
+        kls, ldesc, eq = O.line_extract(gray[t], nlines) if lines else empty_kl
+        cur["mvKeylinesUn"], cur["mLdesc"], cur["mvKeyLineFunctions"] = kls, ldesc, eq
+        t0 = lap("LINEextractor()", t0)
+        L4 = np.stack([kls[k] for k in ("startPointX", "startPointY", "endPointX", "endPointY")], 1).astype(np.float32) if len(kls) else np.zeros((0, 4), np.float32)
+        cur["fans"] = O.lil_pair(L4, 20.0, np.float32(np.pi / 4), w, h)
+        t0 = lap("CPartiallyRecoverConnectivity", t0)
+        g = O.frame_glue(kls, cur["fans"], depth[t], cam, seed=1 + first + t)
+        cur["lines3d"], cur["planes"], cur["lineNo"], cur["cross3d"] = g["lines3d"], g["planes"], g["lineNo"], g["cross3d"]
+        t0 = lap("isLineGood+fans+planes", t0)
+        cur["mvKeysUn"], cur["mvDepth"], cur["mvuRight"] = O.frame_post_rgbd(cur["mvKeys"], depth[t], cam)
+        O.grid_build(cur["mvKeysUn"], bounds)
+        t0 = lap("Undistort+StereoFromRGBD+Grid", t0)
+        for k in ("match", "lm12", "lassigned", "plane_assoc"):
+            cur[k] = np.zeros(0, np.int32)
+        if last is not None and len(cur["mvKeys"]):
+            lm = 0
+            if lines:
+                lm, cur["lm12"], cur["lassigned"] = O.search_by_geom_appearance(last["mvKeylinesUn"], last["mLdesc"], kls, ldesc,
+                                                                                np.ones(len(last["mvKeylinesUn"]), np.uint8), 0.95,
+                                                                                (bounds[0], bounds[2], bounds[1], bounds[3]))
+            t0 = lap("SearchByGeomNApearance", t0)
+
+            def project(th):
+                ku = last["mvKeysUn"]
+                q = np.zeros(len(ku), O.PROJQUERY_DTYPE)
+                q["u"], q["v"] = ku["x"], ku["y"]
+                q["radius"] = np.float32(th) * scale[ku["octave"]]
+                q["ur"] = last["mvuRight"]
+                q["min_level"], q["max_level"] = ku["octave"] - 1, ku["octave"] + 1
+                q["angle"], q["blocks"] = ku["angle"], 1
+                return O.search_by_projection_last(cur["mvKeysUn"], cur["mDescriptors"], cur["mvuRight"], bounds, q, last["mDescriptors"], None, True)
+            nm, cur["match"], _ = project(15)
+            t0 = lap("SearchByProjection(cur,last)", t0)
+            if nm + lm < 20:
+                nm, cur["match"], _ = project(30)
+                t0 = lap("SearchByProjection retry", t0)
+            npl, nmap = len(cur["planes"]), len(last["planes"])
+            if npl and nmap:
+                pts = np.zeros((npl, 15), np.float64)
+                pts[:, 0:6] = cur["lines3d"][cur["lineNo"][:, 0]]
+                pts[:, 6:12] = cur["lines3d"][cur["lineNo"][:, 1]]
+                pts[:, 12:15] = cur["cross3d"]
+                _, cur["plane_assoc"] = O.associate_planes(cur["planes"], pts, last["planes"], 0.05, 0.999, 1)
+            t0 = lap("AssociatePlanesByBoundary", t0)
+        if frame_ms is not None:
+            frame_ms.append((time.perf_counter() - tf) * 1e3)
+        out.append(cur)
+        last = cur
+    return out
+
+
+def compare(got, ref, what=""):
+    """Bit-for-bit comparison of one frame's dropin_main results with the oracle's; raises AssertionError naming the array."""
+    for name, _ in SECTIONS:
+        a, b = got[name], ref[name]
+        if b.ndim > 1:
+            b = b.reshape(-1) if b.dtype.names is None else b
+        a = a.reshape(-1) if a.dtype.names is None else a
+        b = np.ascontiguousarray(b).reshape(-1) if b.dtype.names is None else b
+        assert a.shape == b.shape, f"{what}{name}: {a.shape} vs oracle {b.shape}"
+        assert a.tobytes() == np.ascontiguousarray(b).astype(a.dtype, copy=False).tobytes(), f"{what}{name} differs from the oracle"
