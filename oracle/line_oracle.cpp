@@ -286,6 +286,7 @@ struct Lsd {
             if (y == 6) { const double c = x * x * x; return c * c; }
             double r = 1; for (int i = 0; i < (int)y; ++i) r *= x; return r;
         }
+        if (y == 1.0) return x;   // exact in any libm
         return psl_pow_pos(x, y);
     }
     static double m_sinh(double x) { return g_nfa_math ? psl_sinh_small(x) : std::sinh(x); }

@@ -32,6 +32,8 @@ struct pslfe_line {
     float4* d_trig = nullptr;
     float2* d_seedt = nullptr;
     uint32_t* d_reg = nullptr;
+    LsdnTables NT = {};           // LSD_REFINE_ADV: log_gamma / log(p) tables of nfa() (NT.lg in HBM)
+    double* d_lgamma = nullptr;
     double* d_rects = nullptr;    // LSD_REFINE_ADV: rectangles of k_lsd_grow3 for k_lsd_nfa
     int* d_nrect = nullptr;
     float* d_segtmp = nullptr;
@@ -62,7 +64,8 @@ struct pslfe_line {
         hipFree(d_trig); d_trig = nullptr;
         hipFree(d_seedt); d_seedt = nullptr;
         hipFree(d_in); hipFree(d_scaled); hipFree(d_angdeg); hipFree(d_modgrad); hipFree(d_reg);
-        hipFree(d_seg); hipFree(d_nseg); hipFree(d_rects); hipFree(d_nrect); hipFree(d_segtmp); hipFree(d_keep);
+        hipFree(d_seg); hipFree(d_nseg); hipFree(d_rects); hipFree(d_nrect); hipFree(d_segtmp); hipFree(d_keep); hipFree(d_lgamma);
+        d_lgamma = nullptr;
         d_in = nullptr; d_scaled = nullptr; d_angdeg = nullptr; d_modgrad = nullptr; d_reg = nullptr;
         d_seg = nullptr; d_nseg = nullptr; d_rects = nullptr; d_nrect = nullptr; d_segtmp = nullptr; d_keep = nullptr;
         gw = gh = 0;   // no geometry is prepared any more: the next call allocates again (or fails again) instead of
@@ -151,6 +154,24 @@ struct pslfe_line {
         PSL_ALLOC(d_nrect, F * sizeof(int));
         PSL_ALLOC(d_segtmp, (size_t)Q.maxseg * 4 * sizeof(float) * F);
         PSL_ALLOC(d_keep, (size_t)Q.maxseg * F);
+        {   // nfa() tables: the same functions the device would evaluate, here on the host (bit-identical: single IEEE operations)
+            const int lgn = 1 << 16;
+            std::vector<double> lg((size_t)lgn, 0.0);
+            for (int i = 1; i < lgn; ++i) lg[i] = lsdn_log_gamma((double)i);
+            double pj = Q.p;
+            for (int j = 0; j < PSL_NFA_NP; ++j, pj = pj / 2) {
+                lg.push_back(0);  // placeholders, filled below: the three log tables follow the log_gamma table in the same allocation
+            }
+            lg.resize((size_t)lgn + 3 * PSL_NFA_NP);
+            pj = Q.p;
+            for (int j = 0; j < PSL_NFA_NP; ++j, pj = pj / 2) {
+                lg[(size_t)lgn + j] = psl_log(pj); lg[(size_t)lgn + PSL_NFA_NP + j] = psl_log(1.0 - pj); lg[(size_t)lgn + 2 * PSL_NFA_NP + j] = psl_log10(pj);
+            }
+            PSL_ALLOC(d_lgamma, lg.size() * sizeof(double));
+            const hipError_t e_ = hipMemcpy(d_lgamma, lg.data(), lg.size() * sizeof(double), hipMemcpyHostToDevice);
+            if (e_ != hipSuccess) return fail_prepare(e_, "d_lgamma (upload)");
+            NT.lg = d_lgamma; NT.logs = d_lgamma + lgn; NT.lg_n = lgn; NT.p0 = Q.p; NT.log_nt = Q.log_nt;
+        }
         const size_t N = PSL_MERGE_NMAX;
         PSL_ALLOC(M.lines0, F * N * 4 * sizeof(float));
         PSL_ALLOC(M.lines1, F * N * 4 * sizeof(float));
@@ -215,7 +236,7 @@ struct pslfe_line {
             // a few hundred rectangles per frame: 64 workgroups x 4 waves cover a single frame in one or two passes, and a
             // many-frames launch fills the chip by frames
             const unsigned chunks = F >= 64 ? 16 : 64;
-            k_lsd_nfa<<<dim3(chunks, F), 256, 0, st>>>(P, d_angdeg, d_rects, d_nrect, d_segtmp, d_keep);
+            k_lsd_nfa<<<dim3(chunks, F), 256, 0, st>>>(P, NT, d_angdeg, d_rects, d_nrect, d_segtmp, d_keep);
             k_lsd_emit<<<F, 256, 0, st>>>(P, d_nrect, d_segtmp, d_keep, d_seg, d_nseg);
             PSL_STAGE_END(ctx, "line.lsd_nfa");
         }

@@ -190,7 +190,7 @@ struct pslfe_orb {
         gw = gh = 0;
         last_nframes = 0;
         const int rc_alloc = allocate(Q, w, h, pyr_off, blur_off, cellcap);
-        if (rc_alloc) { release(); return rc_alloc; }
+        if (rc_alloc) { release(); (void)hipGetLastError(); return rc_alloc; }  // the failed hipMalloc must not surface in a later hipGetLastError()
         P = Q;
         gw = w; gh = h;
         return PSLFE_OK;

@@ -13,6 +13,18 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    """A process that uses both PyTorch and libpslfe on the GPU (tests/test_gather_gpu.py, as bench.py) must load PyTorch - and
+    with it PyTorch's copy of the HIP runtime - FIRST: loaded after libpslfe it finds no device."""
+    m = session.config.getoption("-m") or ""
+    if "gpu" in m and "not gpu" not in m:
+        try:
+            import torch
+            torch.cuda.is_available()
+        except Exception:
+            pass
+
+
 @pytest.fixture(scope="session")
 def oracle():
     import oracle_lib

@@ -39,7 +39,7 @@ def main():
     orc = oracle_lib.OracleORB(1000, 1.2, 8, 20, 7)
     k0, d0 = orc(sc.gray(0))
     k1, d1 = orc(sc.gray(1))
-    scale = np.cumprod(np.concatenate([[np.float32(1.0)], np.full(7, 1.2, np.float64)])).astype(np.float32)
+    scale = sf.orb_scale_factors()
     q = np.zeros(len(k0), oracle_lib.PROJQUERY_DTYPE)
     q["u"], q["v"] = k0["x"], k0["y"]
     q["radius"] = np.float32(15.0) * scale[k0["octave"]]

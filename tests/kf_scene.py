@@ -5,7 +5,7 @@ import numpy as np
 import synth_frames as sf
 
 BOUNDS = (0.0, 0.0, 640.0, 480.0)
-SCALE = np.cumprod(np.concatenate([[np.float32(1.0)], np.full(7, 1.2, np.float64)])).astype(np.float32)
+SCALE = __import__("synth_frames").orb_scale_factors()
 SIGMA2 = (SCALE * SCALE).astype(np.float32)
 INV_SIGMA2 = (np.float32(1.0) / SIGMA2).astype(np.float32)
 

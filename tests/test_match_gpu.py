@@ -22,7 +22,7 @@ def _frames():
 def make_queries(kps, desc, rng, th=15.0, jitter=2.0, p_block=0.7, with_ur=False):
     import psl_slam_amd as P
     scale = (np.float32(1.2) ** np.arange(8)).astype(np.float32)
-    scale = np.cumprod(np.concatenate([[np.float32(1.0)], np.full(7, 1.2, np.float64)])).astype(np.float32)
+    scale = sf.orb_scale_factors()
     q = np.zeros(len(kps), P.PROJQUERY_DTYPE)
     q["u"] = kps["x"] + rng.uniform(-jitter, jitter, len(kps)).astype(np.float32)
     q["v"] = kps["y"] + rng.uniform(-jitter, jitter, len(kps)).astype(np.float32)

@@ -31,7 +31,8 @@ def bench_kernels():
 
 
 def scale_factors():
-    return np.cumprod(np.concatenate([[np.float32(1.0)], np.full(NLEVELS - 1, SCALE, np.float64)])).astype(np.float32)
+    import synth_frames as sf
+    return sf.orb_scale_factors(NLEVELS, SCALE)
 
 
 class BatchPipeline:

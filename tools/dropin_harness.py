@@ -91,7 +91,8 @@ def oracle_sequence(gray, depth, nfeatures, nlines, stage_ms=None, first=0, line
     n, h, w = gray.shape
     cam = camera(w)
     orb = O.OracleORB(nfeatures, 1.2, 8, 20, 7)
-    scale = np.cumprod(np.concatenate([[np.float32(1.0)], np.full(7, 1.2, np.float64)])).astype(np.float32)
+    import synth_frames as sf
+    scale = sf.orb_scale_factors()
     b = O.image_bounds(cam, w, h)  # mnMinX, mnMinY, mnMaxX, mnMaxY
     bounds = tuple(float(x) for x in b)
     out, last = [], None
@@ -167,4 +168,10 @@ def compare(got, ref, what=""):
         a = a.reshape(-1) if a.dtype.names is None else a
         b = np.ascontiguousarray(b).reshape(-1) if b.dtype.names is None else b
         assert a.shape == b.shape, f"{what}{name}: {a.shape} vs oracle {b.shape}"
-        assert a.tobytes() == np.ascontiguousarray(b).astype(a.dtype, copy=False).tobytes(), f"{what}{name} differs from the oracle"
+        b = np.ascontiguousarray(b).astype(a.dtype, copy=False)
+        if a.tobytes() != b.tobytes():
+            detail = ""
+            if a.dtype.names is None:
+                bad = np.flatnonzero(a.view(np.uint8).reshape(len(a), -1).any(1) | True) if False else np.flatnonzero(a != b)
+                detail = f": {len(bad)} of {len(a)} entries, first at {bad[:8].tolist()}: got {a[bad[:8]].tolist()} oracle {b[bad[:8]].tolist()}"
+            raise AssertionError(f"{what}{name} differs from the oracle{detail}")

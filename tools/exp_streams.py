@@ -13,7 +13,7 @@ def run(B, N, steps=20, warmup=3):
     frames_d = torch.from_numpy(frames_h).to(dev)
     b = B // N
     pipes = []
-    scale_t = torch.tensor(np.cumprod(np.concatenate([[np.float32(1.0)], np.full(7, 1.2, np.float64)])).astype(np.float32), device=dev)
+    scale_t = torch.tensor(__import__("synth_frames").orb_scale_factors(), device=dev)
     for i in range(N):
         st = torch.cuda.Stream(dev)
         ctx = P.Context(0, st.cuda_stream)

@@ -13,6 +13,17 @@ import numpy as np
 SEED = 20250418
 
 
+def orb_scale_factors(nlevels=8, scale_factor=1.2):
+    """mvScaleFactor as ORBextractor::ORBextractor builds it (src/ORBextractor.cc:417-424): a vector<float> whose entry i is
+    entry i-1 times the DOUBLE member scaleFactor (include/ORBextractor.h:98), itself the float argument 1.2f widened - the
+    product is rounded to float at every level."""
+    sf = np.float64(np.float32(scale_factor))
+    s = [np.float32(1.0)]
+    for _ in range(nlevels - 1):
+        s.append(np.float32(np.float64(s[-1]) * sf))
+    return np.array(s, np.float32)
+
+
 def _smooth_noise(rng, h, w, sigma_px, amp):
     from scipy.ndimage import gaussian_filter
     n = rng.standard_normal((h, w)).astype(np.float32)
