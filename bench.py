@@ -66,7 +66,10 @@ STAGE_BYTES_PER_FRAME = {
     "line.lsd_scale": WH + 8 * 196608,                 # gray read + f64 working image write
     "line.lsd_grad": 8 * 196608 + 2 * 8 * 196608,      # working image read + angle & modgrad write
     "line.lsd_grow": 2 * 8 * 196608 + 2 * 8 * 196608 + 393216,  # angle & modgrad read + coordinate list w+r + used map
-    "line.lsd_nfa": 4 * 196608 + 400 * (64 + 17),      # angle map read once + rectangles in, segments out (not in §8(d): refine mode)
+    # LSD_REFINE_ADV (not in §8(d)'s accounting, which predates the refine mode): per launch of a phase the angle map is read once
+    # and the rectangle state (96 B) read and written; the stage is launched 6 times per step (first test + 5 phases)
+    "line.nfa_count": 4 * 196608 + 400 * (96 + 40),
+    "line.nfa_eval": 400 * (96 + 40 + 96),
     "line.merge": 2 * 16 * 500,
     "line.lbd_pre": WH + 4 * WH,                       # gray read, Sobel (dx, dy) s16 write (the blurred image stays in LDS)
     "line.lbd": 5040000 + 20000,                       # LSR gathers + outputs
@@ -82,12 +85,13 @@ STAGE_KERNELS = {
     "orb.blur": [("k_blur7", 1)], "orb.describe": [("k_orient_describe", 1)],
     "match.grid": [("k_frame_import", 1), ("k_build_grid", 1)], "match.window": [("k_window_eval", 1), ("k_window_resolve<0, 4096, 1024>", 1)],
     "line.lsd_scale": [("k_lsd_scale_tiled", 1)], "line.lsd_grad": [("k_lsd_grad", 1)], "line.lsd_grow": [("k_lsd_grow3", 1)],
-    "line.lsd_nfa": [("k_lsd_nfa", 1), ("k_lsd_emit", 1)],
+    "line.nfa_count": [("k_lsd_nfa_count<%d>" % ph, 1) for ph in (-2, -1, 0, 1, 2, 3)],
+    "line.nfa_eval": [("k_lsd_nfa_eval<%d>" % ph, 1) for ph in (-2, -1, 0, 1, 2, 3)] + [("k_lsd_nfa_select<%d>" % ph, 1) for ph in (-2, -1, 0, 1, 2, 3)],
     "line.merge": [("k_line_merge<512>", 1), ("k_line_merge<1024>", 1)], "line.lbd_pre": [("k_lbd_pre", 1)], "line.lbd": [("k_lbd", 1)], "line.pair": [("k_lil_pair", 1)],
     "line.match": [("k_line_match_batch", 1)], "line.good": [("k_line_good", 1)], "line.planes": [("k_fans_planes", 1)],
 }
 STAGE_NAMES = ["orb.pyramid", "orb.fast", "orb.octree", "orb.blur", "orb.describe", "match.grid", "match.window", "line.lsd_scale",
-               "line.lsd_grad", "line.lsd_grow", "line.lsd_nfa", "line.merge", "line.lbd_pre", "line.lbd", "line.pair", "line.match", "line.good",
+               "line.lsd_grad", "line.lsd_grow", "line.nfa_count", "line.nfa_eval", "line.merge", "line.lbd_pre", "line.lbd", "line.pair", "line.match", "line.good",
                "line.planes", "gather.pack"]
 
 
@@ -150,6 +154,20 @@ def depth_f32(depth_u16):
     pslfe_depth_to_float_device produces, so HBM-resident and --host-io runs see identical depth."""
     import oracle_lib
     return oracle_lib.depth_to_float(np.ascontiguousarray(depth_u16), np.float32(1.0) / np.float32(5000.0))
+
+
+class stdout_to_stderr:
+    """RCCL prints a version banner on STDOUT when a communicator is created; the contract is one JSON line there."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *a):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
 
 
 def seed_for(rank):
@@ -259,7 +277,8 @@ def main():
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        with stdout_to_stderr():
+            dist.init_process_group("nccl", device_id=dev)
 
     import psl_slam_amd as P
     from importlib import import_module
@@ -320,17 +339,20 @@ def main():
             t = torch.from_numpy(uid.copy()).to(dev)
             dist.broadcast(t, 0)
             return t.cpu().numpy()
-        gather = mg.RecordGather(ctx, layout, B, rank, world, dev, bcast)
+        with stdout_to_stderr():
+            gather = mg.RecordGather(ctx, layout, B, rank, world, dev, bcast)
+            step()   # the first exchange initialises the communicator's channels
+            gather.wait()
         if args.host_io:
             rec_host = torch.empty((B, layout.bytes), dtype=torch.uint8).pin_memory()
 
-    def read_stages():
+    def read_stages(nsteps):
         out = {}
         for s in STAGE_NAMES:
             for c in pipe.contexts():
                 ms, n = c.stage_time(s)
                 if n:
-                    out[s] = {"ms_per_launch": ms / n, "launches": n}
+                    out[s] = {"ms_per_launch": ms / n, "launches": n, "steps": nsteps}
         return out
 
     # Warm-up, with every stage timed: finds the dominant stage.  Each timed stage puts two HIP event records between
@@ -341,7 +363,7 @@ def main():
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize(dev)
-    warm = read_stages()
+    warm = read_stages(max(1, args.warmup))
     dom = max(warm, key=lambda s: warm[s]["ms_per_launch"])
     for c in pipe.contexts():
         c.profile_reset()
@@ -363,7 +385,7 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    dom_stage = read_stages()[dom]  # the dominant kernel over exactly the timed steps
+    dom_stage = read_stages(args.steps)[dom]  # the dominant kernel over exactly the timed steps
 
     # ---- parity: frames of the LAST TIMED STEP against the oracle (bit for bit); a mismatch fails the run
     nchk = 0
@@ -392,7 +414,7 @@ def main():
     if gather is not None:
         gather.wait()
     torch.cuda.synchronize(dev)
-    stages = read_stages()
+    stages = read_stages(min(args.steps, 5))
     for c in pipe.contexts():
         c.profile(False)
     stages[dom] = dom_stage
@@ -431,6 +453,7 @@ def main():
                                   "achieved_GBs": round(fps / world * per_frame / 1e9, 2),
                                   "frac_of_8TBs": round(fps / world * per_frame / 1e9 / HBM_PEAK_GBS, 5)},
             "stages_ms_per_launch": {k: round(v["ms_per_launch"], 4) for k, v in stages.items()},
+            "stages_ms_per_step": {k: round(v["ms_per_launch"] * v["launches"] / max(1, v["steps"]), 4) for k, v in stages.items()},
             "parity_checked_frames": nchk,
         }
         if cpu is not None:

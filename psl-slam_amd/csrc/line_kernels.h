@@ -667,7 +667,7 @@ __device__ int lsdw_refine(const LsdW& F, int reg_size, double reg_angle, double
     return reg_size;
 }
 
-#define PSL_LSD_RECT_F64 8   // doubles per rectangle record handed to the NFA kernel: x1 y1 x2 y2 width theta dx dy
+#define PSL_LSD_RECT_F64 12  // doubles per rectangle record handed to the NFA kernels: x1 y1 x2 y2 width theta dx dy (k_lsd_grow3) | prec p log_nfa pad
 
 // flsd()'s output step (+0.5, / SCALE, to float) followed by the contrib wrapper's checkLineExtremes
 // (Thirdparty/line_descriptor/src/LSDDetector_custom.cpp:111-138)

@@ -8,10 +8,8 @@
 // rejected rectangle releases nothing: it does not feed back into the region growing.  k_lsd_grow3 therefore only
 // records the rectangles (in seed order) and this file validates them afterwards with ONE WAVE PER RECTANGLE -
 // thousands of independent waves per launch instead of a longer serial chain per frame:
-//   k_lsd_nfa   wave = rectangle: pixel counts by the lanes (rows or columns of the scan, whichever is longer),
-//               the five trial rectangles of one rect_improve phase evaluated together (their geometry does
-//               not depend on each other's outcome; the two "finer precision" phases share ONE pixel pass for
-//               all five tolerances), nfa() of trial j on lane j;
+//   k_lsd_nfa_count / k_lsd_nfa_eval  one pair of launches per rect_improve phase (see below): pixel scans with one wave per
+//               (rectangle, trial), nfa() with one THREAD per (rectangle, trial);
 //   k_lsd_emit  workgroup = frame: ordered compaction of the accepted segments.
 // rect_nfa() is reproduced as OpenCV 3.x behaves, not as the paper describes it: corners truncated to int, edge
 // slopes by INTEGER division, the second slopes use `tailp->p.x` where the y coordinate was meant, and a row outside
@@ -194,26 +192,40 @@ struct LsdnTables {
 
 __device__ __forceinline__ double lsdn_lg(const LsdnTables& T, int i) { return i < T.lg_n ? T.lg[i] : lsdn_log_gamma((double)i); }
 
-// The truncation test of the binomial tail, `err < tolerance * |-log10(bin_tail) - logNT| * bin_tail`, is what an iteration of
-// nfa() costs (a pow and a log10 in double: ~500 instructions beside ~40 for the recurrence).  It only decides WHERE the
-// series stops, so it is first evaluated with the hardware's f32 log2 / exp2 and explicit error margins: the estimate of err is
-// within 1e-3 relative (m - m^q and 1 - m do not cancel for m < 1/7) and the logarithm within 1e-5 absolute; a comparison that
-// these margins decide is the comparison the exact arithmetic makes, anything closer falls back to the exact test.
-// returns 1 = stop, 0 = go on, -1 = undecided
+// The truncation test of the binomial tail, `err < tolerance * |-log10(bin_tail) - logNT| * bin_tail` with
+// err = term * ((1 - m^q) / (1 - m) - 1) = term * (m - m^q) / (1 - m), is what an iteration of nfa() costs (a pow and a log10 in
+// double: ~500 instructions beside ~15 for the recurrence).  It only decides WHERE the series stops, so it is decided from
+// rigorous bounds first, in two stages, and evaluated exactly only when they leave it open:
+//   stage 1 (no transcendental): m <= (m - m^q) / (1 - m) <= m / (1 - m) for q >= 2 (m < 1/7), and log10(bin_tail) lies between
+//           its binade's end points; all but the last few terms before the stop are decided here;
+//   stage 2: m^q and log2 of the mantissa from the hardware's f32 exp2 / log2: err within 1e-3 relative (m - m^q and 1 - m do
+//           not cancel), the logarithm within 1e-5 absolute.
+// A comparison that the margins decide is the comparison the exact arithmetic makes.  returns 1 = stop, 0 = go on, -1 = undecided
 __device__ __forceinline__ int lsdn_tail_test_fast(double term, double bin_tail, double mult_term, int q, double log_nt) {
-    const float m = (float)mult_term;
-    const float pw = q == 1 ? m : (q == 2 ? m * m : __builtin_amdgcn_exp2f((float)q * __builtin_amdgcn_logf(m)));
-    const float A = (m - pw) / (1.0f - m);
-    const double errE = term * (double)A;
     const unsigned long long bits = (unsigned long long)__double_as_longlong(bin_tail);
     const int e = (int)((bits >> 52) & 0x7ff) - 1023;
-    if (e <= -1022 || e >= 1024) return -1;  // subnormal / non-finite: exact path
-    const float fm = __longlong_as_double((long long)((bits & 0x000fffffffffffffull) | 0x3ff0000000000000ull));
+    if (e <= -1022 || e >= 1024 || q < 2) return -1;  // subnormal / non-finite sums, and q == 1 (err is an exact 0 there): exact path
+    const double tb = 0.1 * bin_tail;
+    {   // stage 1
+        const double a0 = -(double)e * 0.30102999566398120 - log_nt, a1 = -(double)(e + 1) * 0.30102999566398120 - log_nt;  // -log10(bt) - logNT in (a1, a0]
+        const double f0 = fabs(a0), f1 = fabs(a1);
+        const double Lhi = (f0 > f1 ? f0 : f1) + 1e-9, Llo = (a0 > 0) == (a1 > 0) ? (f0 < f1 ? f0 : f1) - 1e-9 : 0.0;
+        // the reference's `(1 - pow) / (1 - m) - 1` cancels to about m with an ABSOLUTE rounding error of a few 1e-16: the slack
+        // 5e-16 covers it (it matters for tiny m); 1 / (1 - m) <= 1 + 1.2 m for m <= 1/7
+        const double errL = term * (mult_term - 5e-16), errU = term * (mult_term * (1.0 + 1.2 * mult_term) + 5e-16);
+        if (errU * 1.000001 < tb * (Llo > 0 ? Llo : 0.0)) return 1;
+        if (errL * 0.999999 >= tb * Lhi) return 0;
+    }
+    const float m = (float)mult_term;
+    const float pw = q == 2 ? m * m : __builtin_amdgcn_exp2f((float)q * __builtin_amdgcn_logf(m));
+    const float A = (m - pw) / (1.0f - m);
+    const double errE = term * (double)A, slack = term * 5e-16;
+    const float fm = (float)__longlong_as_double((long long)((bits & 0x000fffffffffffffull) | 0x3ff0000000000000ull));
     const double l10 = ((double)e + (double)__builtin_amdgcn_logf(fm)) * 0.30102999566398120;
     const double Lv = fabs(-l10 - log_nt);
     const double lo = Lv - 1e-5, hi = Lv + 1e-5;
-    if (errE * 1.001 < 0.1 * (lo > 0 ? lo : 0.0) * bin_tail) return 1;
-    if (errE * 0.999 >= 0.1 * hi * bin_tail) return 0;
+    if (errE * 1.001 + slack < tb * (lo > 0 ? lo : 0.0)) return 1;
+    if (errE * 0.999 - slack >= tb * hi) return 0;
     return -1;
 }
 
@@ -253,13 +265,6 @@ __device__ __forceinline__ double lsdn_nfa(const LsdnTables& T, int n, int k, do
     return PSL_DSUB(-psl_log10(bin_tail), log_nt);
 }
 
-// nfa() of up to five (n, k, p) triples, trial j on lane j (lanes >= ntr idle); lane j keeps its value
-__device__ __forceinline__ double lsdn_nfa_lanes(const LsdnTables& T, int nj, int kj, double pj, int ntr, int lane) {
-    double mine = 0;
-    if (lane < ntr) mine = lsdn_nfa(T, nj, kj, pj);
-    return mine;
-}
-
 // one step of the cumulative change a rect_improve phase applies to its trial rectangle (phase 0: narrower, 1 / 2: one side)
 __device__ __forceinline__ void lsdn_shrink(LsdnRect& r, int phase) {
     const double delta = 0.5, delta_2 = 0.25;
@@ -273,98 +278,206 @@ __device__ __forceinline__ void lsdn_shrink(LsdnRect& r, int phase) {
     r.width = PSL_DSUB(r.width, delta);
 }
 
-// rect_improve(): returns log_nfa, *rec = the improved rectangle.  All lanes hold the same values.  The five trial rectangles
-// of a phase do not depend on each other's outcome (r is changed cumulatively, rec only receives copies), so their pixel counts
-// are taken one after the other (wave-parallel each), their nfa() values together (trial j on lane j), and the chosen trial is
-// rebuilt by replaying its steps - nothing but (n, k) per trial is kept, in LDS (sc: 10 ints of this wave).
-__device__ __forceinline__ double lsdn_rect_improve(const float* __restrict__ ang, int W, int H, const LsdnTables& T, LsdnRect* rec, int lane, int* sc) {
-    LsdnGeom G;
-    double log_nfa;
-    {
-        int n1, k1;
-        lsdn_geom(*rec, H, &G);
-        lsdn_count<1>(ang, W, G, rec->theta, &rec->prec, lane, &n1, &k1);
-        log_nfa = lsdw_lane_f64(lsdn_nfa_lanes(T, n1, k1, rec->p, 1, lane), 0);
-    }
-    if (log_nfa > 0) return log_nfa;
-#pragma unroll 1
-    for (int phase = -1; phase <= 3; ++phase) {
-        int ntr = 0;
-        double pj = rec->p;   // this lane's trial probability
-        if (phase == -1 || phase == 3) {
-            // finer precision: one geometry, five tolerances p / 2^(j+1), ONE pass over the pixels
-            if (phase == 3 && !(PSL_DSUB(rec->width, 0.5) >= 0.5)) break;   // the guard holds for all five trials or for none
-            double pr[5], pp = rec->p;
-#pragma unroll
-            for (int j = 0; j < 5; ++j) { pp = pp / 2; pr[j] = PSL_DMUL(pp, PSL_PI); if (lane == j) pj = pp; }
-            int tot, kk[5];
-            lsdn_geom(*rec, H, &G);
-            lsdn_count<5>(ang, W, G, rec->theta, pr, lane, &tot, kk);
-            if (lane == 0) {
-#pragma unroll
-                for (int j = 0; j < 5; ++j) { sc[j] = tot; sc[5 + j] = kk[j]; }
-            }
-            ntr = 5;
-        } else {
-            LsdnRect r = *rec;
-#pragma unroll 1
-            for (int j = 0; j < 5; ++j) {
-                if (!(PSL_DSUB(r.width, 0.5) >= 0.5)) break;   // the guard only ever turns false: the width shrinks monotonically
-                lsdn_shrink(r, phase);
-                int nn, kk;
-                lsdn_geom(r, H, &G);
-                lsdn_count<1>(ang, W, G, r.theta, &r.prec, lane, &nn, &kk);
-                if (lane == 0) { sc[j] = nn; sc[5 + j] = kk; }
-                ntr = j + 1;
-            }
-        }
-        if (ntr) {
-            __builtin_amdgcn_wave_barrier();
-            const int jl = lane < 5 ? lane : 0;
-            const double mine = lsdn_nfa_lanes(T, sc[jl], sc[5 + jl], pj, ntr, lane);
-            __builtin_amdgcn_wave_barrier();
-            int best = -1;
-#pragma unroll
-            for (int j = 0; j < 5; ++j) {
-                const double vj = lsdw_lane_f64(mine, j);
-                if (j < ntr && vj > log_nfa) { log_nfa = vj; best = j; }
-            }
-            if (best >= 0) {
-                if (phase == -1 || phase == 3) {
-                    double pp = rec->p;
-                    for (int j = 0; j <= best; ++j) pp = pp / 2;
-                    rec->p = pp; rec->prec = PSL_DMUL(pp, PSL_PI);
-                } else {
-                    LsdnRect r = *rec;
-                    for (int j = 0; j <= best; ++j) lsdn_shrink(r, phase);
-                    *rec = r;
-                }
-            }
-        }
-        if (log_nfa > 0) return log_nfa;
-    }
-    return log_nfa;
+// ---- rect_improve() as a sequence of launches ---------------------------------------------------------------------------
+// rect_improve() is: first test; then five phases (finer precision; narrower; one side; the other side; finer precision again),
+// each of five trial rectangles, returning as soon as a phase ends with log_nfa > 0.  The trials of a phase do not depend on
+// each other's outcome (r changes cumulatively, rec only receives copies), and the two halves of a trial parallelise in
+// opposite ways, so every phase is TWO launches over all rectangles that are still undecided:
+//   k_lsd_nfa_count<PH>  wave = (rectangle, trial): the pixel scan (for the finer-precision phases wave = rectangle, one scan
+//                        for all five tolerances) -> (n, k) per trial;
+//   k_lsd_nfa_eval<PH>   THREAD = (rectangle, trial): nfa(n, k, p) is scalar code - thousands of independent evaluations
+//                        per launch instead of one per wave - drawn from a shared counter, because their lengths differ widely;
+//   k_lsd_nfa_select<PH> thread = rectangle: the reference's sequential `if (v > log_nfa)` selection over the trials, the
+//                        chosen trial rebuilt by replaying its steps, accept / keep going / reject.
+// State per rectangle: PSL_LSD_RECT_F64 doubles in `rects` (x1 y1 x2 y2 width theta dx dy | prec p log_nfa) and one byte in
+// `keep`: 0 = rejected, 1 = accepted, 2 = undecided.  PH: -2 first test, -1 finer, 0 narrower, 1 / 2 one side, 3 finer again.
+#define PSL_NFA_FIRST (-2)
+
+__device__ __forceinline__ void lsdn_load(const double* __restrict__ r, LsdnRect* rec) {
+    rec->x1 = r[0]; rec->y1 = r[1]; rec->x2 = r[2]; rec->y2 = r[3]; rec->width = r[4]; rec->theta = r[5]; rec->dx = r[6]; rec->dy = r[7];
+    rec->prec = r[8]; rec->p = r[9];
 }
 
-// wave = rectangle; grid (chunks, frames), a workgroup strides over the rectangles of its frame.
-// rects: [F][maxseg][PSL_LSD_RECT_F64] from k_lsd_grow3, nrect: [F]; segtmp: [F][maxseg][4], keep: [F][maxseg]
-__global__ __launch_bounds__(256, 4) void k_lsd_nfa(LineParams P, LsdnTables T, const float* __restrict__ angdeg, const double* __restrict__ rects,
-                                                 const int* __restrict__ nrect, float* __restrict__ segtmp, uint8_t* __restrict__ keep) {
-    __shared__ int s_counts[4][10];
+template <int PH>
+__global__ __launch_bounds__(256, 4) void k_lsd_nfa_count(LineParams P, const float* __restrict__ angdeg, double* __restrict__ rects,
+                                                          const int* __restrict__ nrect, const uint8_t* __restrict__ keep, int2* __restrict__ counts) {
+    constexpr int TR = (PH >= 0 && PH <= 2) ? 5 : 1;   // waves per rectangle
     const int frame = blockIdx.y, lane = threadIdx.x & 63;
     const int cnt = nrect[frame] < P.maxseg ? nrect[frame] : P.maxseg;
-    for (int idx = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6); idx < cnt; idx += (int)gridDim.x * 4) {
+    const float* ang = angdeg + (size_t)frame * P.W * P.H;
+    for (int item = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6); item < cnt * TR; item += (int)gridDim.x * 4) {
+        const int idx = item / TR, j = item - idx * TR;
         const size_t o = (size_t)frame * P.maxseg + idx;
-        const double* r = rects + o * PSL_LSD_RECT_F64;
+        if (PH != PSL_NFA_FIRST && keep[o] != 2) continue;
+        double* rs = rects + o * PSL_LSD_RECT_F64;
         LsdnRect rec;
-        rec.x1 = r[0]; rec.y1 = r[1]; rec.x2 = r[2]; rec.y2 = r[3]; rec.width = r[4]; rec.theta = r[5]; rec.dx = r[6]; rec.dy = r[7];
-        rec.prec = P.prec; rec.p = P.p;
-        const double log_nfa = lsdn_rect_improve(angdeg + (size_t)frame * P.W * P.H, P.W, P.H, T, &rec, lane, s_counts[threadIdx.x >> 6]);
-        if (lane == 0) {
-            const bool ok = log_nfa > 0;  // LOG_EPS = 0
-            keep[o] = ok ? 1 : 0;
-            if (ok) psl_lsd_store_segment(P, rec.x1, rec.y1, rec.x2, rec.y2, segtmp + 4 * o);
+        lsdn_load(rs, &rec);
+        if (PH == PSL_NFA_FIRST) {
+            rec.prec = P.prec; rec.p = P.p;
+            if (lane == 0) { rs[8] = rec.prec; rs[9] = rec.p; }
         }
+        LsdnGeom G;
+        int2* out = counts + o * 5;
+        if (PH == -1 || PH == 3) {       // five tolerances p / 2^(j+1), one geometry, ONE pass over the pixels
+            if (PH == 3 && !(PSL_DSUB(rec.width, 0.5) >= 0.5)) {   // the guard holds for all five trials or for none
+                if (lane < 5) out[lane] = make_int2(-1, 0);
+                continue;
+            }
+            double pr[5], pp = rec.p;
+#pragma unroll
+            for (int t = 0; t < 5; ++t) { pp = pp / 2; pr[t] = PSL_DMUL(pp, PSL_PI); }
+            int tot, kk[5];
+            lsdn_geom(rec, P.H, &G);
+            lsdn_count<5>(ang, P.W, G, rec.theta, pr, lane, &tot, kk);
+            if (lane == 0) {
+#pragma unroll
+                for (int t = 0; t < 5; ++t) out[t] = make_int2(tot, kk[t]);
+            }
+        } else {
+            bool valid = true;
+            if (PH >= 0) {               // trial j = j + 1 cumulative steps, each under the width guard (it only ever turns false)
+                for (int t = 0; t <= j; ++t) {
+                    if (!(PSL_DSUB(rec.width, 0.5) >= 0.5)) { valid = false; break; }
+                    lsdn_shrink(rec, PH);
+                }
+            }
+            int nn = -1, kk = 0;
+            if (valid) {
+                lsdn_geom(rec, P.H, &G);
+                lsdn_count<1>(ang, P.W, G, rec.theta, &rec.prec, lane, &nn, &kk);
+            }
+            if (lane == 0) out[j] = make_int2(nn, kk);
+        }
+    }
+}
+
+// nfa() for every (rectangle, trial) of a frame: THREAD = evaluation, scheduled dynamically.  The binomial tail of nfa() runs
+// for 1 .. ~900 iterations (mean ~40, heavy tail), so a wave that gives every lane ONE evaluation waits for its slowest lane
+// (measured: 10x the mean).  Here the lanes of a workgroup draw evaluations from a shared counter: a lane whose series has
+// stopped idles at most 15 iterations, until the next refill point, where all such lanes finish (log10, store), draw the next
+// item and set it up (three table loads, an exp) together - the hot loop between refill points is only the recurrence, the
+// division and the f32 pre-test.  Results overwrite the (n, k) pair of the trial with the value (a double, -inf for a trial
+// the width guard excludes); k_lsd_nfa_select reads them.
+template <int PH>
+__global__ __launch_bounds__(256) void k_lsd_nfa_eval(LineParams P, LsdnTables T, const double* __restrict__ rects, const int* __restrict__ nrect,
+                                                      const uint8_t* __restrict__ keep, int2* __restrict__ counts) {
+    __shared__ int s_next;
+    const int frame = blockIdx.y;
+    const int cnt = nrect[frame] < P.maxseg ? nrect[frame] : P.maxseg;
+    constexpr int TR = PH == PSL_NFA_FIRST ? 1 : 5;
+    const int nitems = cnt * TR;
+    const int per = (nitems + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int begin = (int)blockIdx.x * per, end = min(begin + per, nitems);
+    if (begin >= end) return;
+    if (threadIdx.x == 0) s_next = begin;
+    __syncthreads();
+    const double log_nt = T.log_nt;
+    double* vals = reinterpret_cast<double*>(counts);
+    // lane state
+    bool running = false, done = false;   // done: the series has stopped, the value is still to be written
+    int n = 0, i = 0;
+    size_t slot = 0;
+    double term = 0, bin_tail = 0, p_term = 0;
+    for (int iter = 0;; ++iter) {
+        if ((iter & 15) == 0) {   // refill point
+            if (done) { vals[slot] = PSL_DSUB(-psl_log10(bin_tail), log_nt); done = false; }
+            for (int tries = 0; tries < 1 && !running; ++tries) {
+                const int item = atomicAdd(&s_next, 1);
+                if (item >= end) break;
+                const int idx = item / TR, j = item - idx * TR;
+                const size_t o = (size_t)frame * P.maxseg + idx;
+                if (PH != PSL_NFA_FIRST && keep[o] != 2) continue;
+                slot = o * 5 + j;
+                const int2 c = counts[slot];
+                if (c.x < 0) { vals[slot] = -__builtin_inf(); continue; }
+                double p = rects[o * PSL_LSD_RECT_F64 + 9];
+                if (PH == -1 || PH == 3) for (int t = 0; t <= j; ++t) p = p / 2;
+                // nfa(): everything before the series
+                n = c.x;
+                const int k = c.y;
+                if (n == 0 || k == 0) { vals[slot] = -log_nt; continue; }
+                int jp = (int)((__double_as_longlong(T.p0) >> 52) & 0x7ff) - (int)((__double_as_longlong(p) >> 52) & 0x7ff);
+                if (jp < 0 || jp >= PSL_NFA_NP || __longlong_as_double(__double_as_longlong(T.p0) - ((long long)jp << 52)) != p) jp = -1;
+                if (n == k) { vals[slot] = PSL_DSUB(-log_nt, PSL_DMUL((double)n, jp >= 0 ? T.logs[2 * PSL_NFA_NP + jp] : psl_log10(p))); continue; }
+                p_term = p / PSL_DSUB(1.0, p);
+                double log1term = PSL_DSUB(PSL_DSUB(lsdn_lg(T, n + 1), lsdn_lg(T, k + 1)), lsdn_lg(T, n - k + 1));
+                log1term = PSL_DADD(PSL_DADD(log1term, PSL_DMUL((double)k, jp >= 0 ? T.logs[jp] : psl_log(p))),
+                                    PSL_DMUL((double)(n - k), jp >= 0 ? T.logs[PSL_NFA_NP + jp] : psl_log(PSL_DSUB(1.0, p))));
+                term = psl_exp(log1term);
+                if (lsdn_double_equal0(term)) {
+                    vals[slot] = (double)k > PSL_DMUL((double)n, p) ? PSL_DSUB(-log1term / 2.30258509299404568402, log_nt) : -log_nt;
+                    continue;
+                }
+                bin_tail = term;
+                i = k + 1;
+                if (i > n) { vals[slot] = PSL_DSUB(-psl_log10(bin_tail), log_nt); continue; }
+                running = true;
+            }
+            if (!__syncthreads_or(running ? 1 : 0)) break;   // nobody in the workgroup has work left (the counter is exhausted)
+        }
+        if (running) {   // one term of the binomial tail
+            const double bin_term = (double)(n - i + 1) / (double)i;
+            const double mult_term = PSL_DMUL(bin_term, p_term);
+            term = PSL_DMUL(term, mult_term);
+            bin_tail = PSL_DADD(bin_tail, term);
+            bool stop = false;
+            if (bin_term < 1) {
+                const int q = n - i + 1;
+                int st = lsdn_tail_test_fast(term, bin_tail, mult_term, q, log_nt);
+                if (st < 0) {
+                    const double pw = q == 1 ? mult_term : psl_pow_pos(mult_term, (double)q);  // pow(x, 1) is exact in any libm
+                    const double err = PSL_DMUL(term, PSL_DSUB(PSL_DSUB(1.0, pw) / PSL_DSUB(1.0, mult_term), 1.0));
+                    st = err < PSL_DMUL(PSL_DMUL(0.1, fabs(PSL_DSUB(-psl_log10(bin_tail), log_nt))), bin_tail) ? 1 : 0;
+                }
+                stop = st != 0;
+            }
+            ++i;
+            if (stop || i > n) { running = false; done = true; }
+        }
+    }
+}
+
+// thread = rectangle: the reference's selection over the trials of the phase, in trial order - `if (v > log_nfa) { log_nfa = v;
+// rec = r; }` - the chosen trial rebuilt by replaying its steps, and the verdict if there is one
+template <int PH>
+__global__ __launch_bounds__(256) void k_lsd_nfa_select(LineParams P, double* __restrict__ rects, const int* __restrict__ nrect,
+                                                        uint8_t* __restrict__ keep, const int2* __restrict__ counts, float* __restrict__ segtmp) {
+    const int frame = blockIdx.y;
+    const int cnt = nrect[frame] < P.maxseg ? nrect[frame] : P.maxseg;
+    const double* vals = reinterpret_cast<const double*>(counts);
+    for (int idx = (int)(blockIdx.x * 256 + threadIdx.x); idx < cnt; idx += (int)gridDim.x * 256) {
+        const size_t o = (size_t)frame * P.maxseg + idx;
+        if (PH != PSL_NFA_FIRST && keep[o] != 2) continue;
+        double* rs = rects + o * PSL_LSD_RECT_F64;
+        LsdnRect rec;
+        lsdn_load(rs, &rec);
+        double logn;
+        int best = -1;
+        if (PH == PSL_NFA_FIRST) logn = vals[o * 5];
+        else {
+            logn = rs[10];
+#pragma unroll
+            for (int t = 0; t < 5; ++t) {
+                const double vt = vals[o * 5 + t];
+                if (vt > logn) { logn = vt; best = t; }
+            }
+        }
+        if (best >= 0) {
+            if (PH == -1 || PH == 3) {
+                double pp = rec.p;
+                for (int t = 0; t <= best; ++t) pp = pp / 2;
+                rec.p = pp; rec.prec = PSL_DMUL(pp, PSL_PI);
+                rs[8] = rec.prec; rs[9] = rec.p;
+            } else if (PH >= 0) {
+                for (int t = 0; t <= best; ++t) lsdn_shrink(rec, PH);
+                rs[0] = rec.x1; rs[1] = rec.y1; rs[2] = rec.x2; rs[3] = rec.y2; rs[4] = rec.width;
+            }
+        }
+        rs[10] = logn;
+        if (logn > 0) {   // LOG_EPS = 0: accepted, with the rectangle as it stands now
+            keep[o] = 1;
+            psl_lsd_store_segment(P, rec.x1, rec.y1, rec.x2, rec.y2, segtmp + 4 * o);
+        } else keep[o] = PH == 3 ? 0 : 2;
     }
 }
 

@@ -38,6 +38,7 @@ struct pslfe_line {
     int* d_nrect = nullptr;
     float* d_segtmp = nullptr;
     uint8_t* d_keep = nullptr;
+    int2* d_counts = nullptr;     // (n, k) of the five trial rectangles of a rect_improve phase
     float* d_seg = nullptr;
     int* d_nseg = nullptr;
     MergeScratch M = {};
@@ -64,7 +65,8 @@ struct pslfe_line {
         hipFree(d_trig); d_trig = nullptr;
         hipFree(d_seedt); d_seedt = nullptr;
         hipFree(d_in); hipFree(d_scaled); hipFree(d_angdeg); hipFree(d_modgrad); hipFree(d_reg);
-        hipFree(d_seg); hipFree(d_nseg); hipFree(d_rects); hipFree(d_nrect); hipFree(d_segtmp); hipFree(d_keep); hipFree(d_lgamma);
+        hipFree(d_seg); hipFree(d_nseg); hipFree(d_rects); hipFree(d_nrect); hipFree(d_segtmp); hipFree(d_keep); hipFree(d_lgamma); hipFree(d_counts);
+        d_counts = nullptr;
         d_lgamma = nullptr;
         d_in = nullptr; d_scaled = nullptr; d_angdeg = nullptr; d_modgrad = nullptr; d_reg = nullptr;
         d_seg = nullptr; d_nseg = nullptr; d_rects = nullptr; d_nrect = nullptr; d_segtmp = nullptr; d_keep = nullptr;
@@ -154,6 +156,7 @@ struct pslfe_line {
         PSL_ALLOC(d_nrect, F * sizeof(int));
         PSL_ALLOC(d_segtmp, (size_t)Q.maxseg * 4 * sizeof(float) * F);
         PSL_ALLOC(d_keep, (size_t)Q.maxseg * F);
+        PSL_ALLOC(d_counts, (size_t)Q.maxseg * 5 * sizeof(int2) * F);
         {   // nfa() tables: the same functions the device would evaluate, here on the host (bit-identical: single IEEE operations)
             const int lgn = 1 << 16;
             std::vector<double> lg((size_t)lgn, 0.0);
@@ -232,13 +235,31 @@ struct pslfe_line {
             PSL_STAGE_END(ctx, "line.lsd_grow");
         }
         if (refine >= 2) {
-            PSL_STAGE_BEGIN(ctx, "line.lsd_nfa");
-            // a few hundred rectangles per frame: 64 workgroups x 4 waves cover a single frame in one or two passes, and a
-            // many-frames launch fills the chip by frames
-            const unsigned chunks = F >= 64 ? 16 : 64;
-            k_lsd_nfa<<<dim3(chunks, F), 256, 0, st>>>(P, NT, d_angdeg, d_rects, d_nrect, d_segtmp, d_keep);
+            // rect_improve + NFA: per phase a pixel-scan launch (wave = rectangle x trial), an nfa() launch (thread = evaluation) and a
+            // selection launch (thread = rectangle), line_kernels3.h.  A few hundred rectangles per frame: a many-frames launch fills
+            // the chip by frames, a single frame by chunks.  (The stage timers record the launches of a phase as they are issued;
+            // with profiling on, every stage costs two event records.)
+            const dim3 gc(F >= 64 ? 8 : 128, F), ge(F >= 64 ? 1 : 8, F), gs(F >= 64 ? 1 : 4, F);
+#define PSL_NFA_PHASE(PH)                                                                                                \
+    {                                                                                                                    \
+        PSL_STAGE_BEGIN(ctx, "line.nfa_count");                                                                          \
+        k_lsd_nfa_count<PH><<<gc, 256, 0, st>>>(P, d_angdeg, d_rects, d_nrect, d_keep, d_counts);                       \
+        PSL_STAGE_END(ctx, "line.nfa_count");                                                                            \
+    }                                                                                                                    \
+    {                                                                                                                    \
+        PSL_STAGE_BEGIN(ctx, "line.nfa_eval");                                                                           \
+        k_lsd_nfa_eval<PH><<<ge, 256, 0, st>>>(P, NT, d_rects, d_nrect, d_keep, d_counts);                              \
+        k_lsd_nfa_select<PH><<<gs, 256, 0, st>>>(P, d_rects, d_nrect, d_keep, d_counts, d_segtmp);                      \
+        PSL_STAGE_END(ctx, "line.nfa_eval");                                                                             \
+    }
+            PSL_NFA_PHASE(PSL_NFA_FIRST)
+            PSL_NFA_PHASE(-1)
+            PSL_NFA_PHASE(0)
+            PSL_NFA_PHASE(1)
+            PSL_NFA_PHASE(2)
+            PSL_NFA_PHASE(3)
+#undef PSL_NFA_PHASE
             k_lsd_emit<<<F, 256, 0, st>>>(P, d_nrect, d_segtmp, d_keep, d_seg, d_nseg);
-            PSL_STAGE_END(ctx, "line.lsd_nfa");
         }
         PSL_HIP(hipGetLastError());
         last_nframes = nframes;

@@ -206,7 +206,7 @@ int main(int argc, char** argv) {
         printf("}");
         if (stage_prof) {
             static const char* names[] = {"orb.pyramid", "orb.fast", "orb.octree", "orb.blur", "orb.describe", "match.grid", "match.window",
-                                          "line.lsd_scale", "line.lsd_grad", "line.lsd_grow", "line.lsd_nfa", "line.merge", "line.lbd_pre", "line.lbd", "line.pair",
+                                          "line.lsd_scale", "line.lsd_grad", "line.lsd_grow", "line.nfa_count", "line.nfa_eval", "line.merge", "line.lbd_pre", "line.lbd", "line.pair",
                                           "line.match", "line.good", "line.planes"};
             printf(", \"gpu_stage_ms_per_frame\": {");
             first = true;
