@@ -89,65 +89,109 @@ __device__ __forceinline__ void lsdn_row_span(const LsdnGeom& G, int y, int W, i
     *xb = (int)(R >= W ? W - 1 : (R < -1 ? -1 : R));
 }
 
-__device__ __forceinline__ int lsdn_wave_sum(int v) {
+// sums / maxima over aligned groups of GL lanes (GL = 16: four scans per wave)
+template <int GL>
+__device__ __forceinline__ int lsdn_group_sum(int v) {
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    for (int o = GL / 2; o > 0; o >>= 1) v += __shfl_xor(v, o);
     return v;
 }
 
-__device__ __forceinline__ int lsdn_wave_max_i(int v) {
+template <int GL>
+__device__ __forceinline__ int lsdn_group_max(int v) {
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { const int u = __shfl_xor(v, o); v = u > v ? u : v; }
+    for (int o = GL / 2; o > 0; o >>= 1) { const int u = __shfl_xor(v, o); v = u > v ? u : v; }
     return v;
 }
 
 // total_pts and, for NP tolerances, alg_pts of rect_nfa().  The scan is a few hundred pixels whose angles sit in L2 / L1: what
 // it costs is memory latency, so the pixels are enumerated as slots (row, offset < widest span) dealt to the lanes round-robin
-// and every lane has four loads in flight - not one dependent load per pixel in a per-row or per-column loop.
-template <int NP>
+// and every lane has four loads in flight - not one dependent load per pixel in a per-row or per-column loop.  A scan is done by
+// a group of GL lanes (`lane` = the lane's index in its group); the groups of a wave scan different rectangles, each lane running
+// its own loops, and only the final sums cross lanes (inside the group).
+template <int NP, int GL>
 __device__ __forceinline__ void lsdn_count(const float* __restrict__ ang, int W, const LsdnGeom& G, double theta, const double* prec, int lane, int* total, int* alg) {
     int al[NP];
 #pragma unroll
     for (int j = 0; j < NP; ++j) al[j] = 0;
+    // isAligned(x, y, theta, prec) per pixel is eight double-precision operations (half rate).  The angle map holds f32 degrees
+    // and the double value is exactly (double)deg * pi/180, so the folded difference is first formed in f32 degrees: its error
+    // against the exact double evaluation is below 1e-3 degrees (theta <= 3 pi: 6e-5 from the conversion, 3e-5 per f32 operation),
+    // and only a pixel within that margin of a tolerance is decided by the exact arithmetic.
+    const float theta_deg = (float)(theta * 57.295779513082320877);
+    float pdeg[NP];
+#pragma unroll
+    for (int j = 0; j < NP; ++j) pdeg[j] = (float)(prec[j] * 57.295779513082320877);
+    auto pixel = [&](float a) {
+        if (a == PSL_LSD_NOTDEF) return;
+        float d = __builtin_fabsf(theta_deg - a);
+        const float d2 = __builtin_fabsf(d - 360.0f);
+        d = d > 270.0f ? d2 : d;
+        bool close = __builtin_fabsf(d - 270.0f) < 2e-3f;   // the fold itself is decided on the exact value near its switch point
+#pragma unroll
+        for (int j = 0; j < NP; ++j) close = close || __builtin_fabsf(d - pdeg[j]) < 2e-3f;
+        if (!close) {
+#pragma unroll
+            for (int j = 0; j < NP; ++j) al[j] += d <= pdeg[j] ? 1 : 0;
+        } else {
+            const double f = lsdg_fold(PSL_DMUL((double)a, PSL_DEG2RAD), theta);
+#pragma unroll
+            for (int j = 0; j < NP; ++j) al[j] += f <= prec[j] ? 1 : 0;
+        }
+    };
     const int nrows = G.yb - G.ya + 1;
-    int tot = 0, wmax = 0;
-    for (int y = G.ya + lane; y <= G.yb; y += 64) {  // lane = row: pixels and widest span
-        int xa, xb;
-        lsdn_row_span(G, y, W, &xa, &xb);
-        const int c = xb - xa + 1;
-        tot += c > 0 ? c : 0;
-        wmax = c > wmax ? c : wmax;
-    }
-    *total = lsdn_wave_sum(tot);
-    wmax = lsdn_wave_max_i(wmax);
-    if (nrows > 0 && wmax > 0) {
-        const int nslots = nrows * wmax, row_step = 64 / wmax, dx_step = 64 - row_step * wmax;
-        int row = lane / wmax, dx = lane - row * wmax;
-        for (int s = lane; s < nslots; s += 256) {
-            float a[4];
+    int tot = 0;
+    if (nrows >= GL) {   // lane = row: the span is computed once per row, four loads of the row in flight
+        for (int y = G.ya + lane; y <= G.yb; y += GL) {
+            int xa, xb;
+            lsdn_row_span(G, y, W, &xa, &xb);
+            const int c = xb - xa + 1;
+            tot += c > 0 ? c : 0;
+            const float* row = ang + y * W;
+            for (int x = xa; x <= xb; x += 4) {
+                float a[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                a[u] = PSL_LSD_NOTDEF;
-                if (s + 64 * u < nslots) {
-                    int xa, xb;
-                    const int y = G.ya + row;
-                    lsdn_row_span(G, y, W, &xa, &xb);
-                    if (dx <= xb - xa) a[u] = ang[y * W + xa + dx];
-                }
-                dx += dx_step; row += row_step;
-                if (dx >= wmax) { dx -= wmax; ++row; }
+                for (int u = 0; u < 4; ++u) a[u] = x + u <= xb ? row[x + u] : PSL_LSD_NOTDEF;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) pixel(a[u]);
             }
+        }
+        *total = lsdn_group_sum<GL>(tot);
+    } else {             // few rows: the pixels as slots (row, offset < widest span) dealt to the lanes round-robin
+        int wmax = 0;
+        for (int y = G.ya + lane; y <= G.yb; y += GL) {
+            int xa, xb;
+            lsdn_row_span(G, y, W, &xa, &xb);
+            const int c = xb - xa + 1;
+            tot += c > 0 ? c : 0;
+            wmax = c > wmax ? c : wmax;
+        }
+        *total = lsdn_group_sum<GL>(tot);
+        wmax = lsdn_group_max<GL>(wmax);
+        if (nrows > 0 && wmax > 0) {
+            const int nslots = nrows * wmax, row_step = GL / wmax, dx_step = GL - row_step * wmax;
+            int row = lane / wmax, dx = lane - row * wmax;
+            for (int s = lane; s < nslots; s += 4 * GL) {
+                float a[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
-                if (a[u] != PSL_LSD_NOTDEF) {
-                    const double f = lsdg_fold(PSL_DMUL((double)a[u], PSL_DEG2RAD), theta);
-#pragma unroll
-                    for (int j = 0; j < NP; ++j) al[j] += f <= prec[j] ? 1 : 0;
+                for (int u = 0; u < 4; ++u) {
+                    a[u] = PSL_LSD_NOTDEF;
+                    if (s + GL * u < nslots) {
+                        int xa, xb;
+                        const int y = G.ya + row;
+                        lsdn_row_span(G, y, W, &xa, &xb);
+                        if (dx <= xb - xa) a[u] = ang[y * W + xa + dx];
+                    }
+                    dx += dx_step; row += row_step;
+                    if (dx >= wmax) { dx -= wmax; ++row; }
                 }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) pixel(a[u]);
+            }
         }
     }
 #pragma unroll
-    for (int j = 0; j < NP; ++j) alg[j] = lsdn_wave_sum(al[j]);
+    for (int j = 0; j < NP; ++j) alg[j] = lsdn_group_sum<GL>(al[j]);
 }
 
 // ---- nfa() ------------------------------------------------------------------------------------------------------------
@@ -283,10 +327,11 @@ __device__ __forceinline__ void lsdn_shrink(LsdnRect& r, int phase) {
 // each of five trial rectangles, returning as soon as a phase ends with log_nfa > 0.  The trials of a phase do not depend on
 // each other's outcome (r changes cumulatively, rec only receives copies), and the two halves of a trial parallelise in
 // opposite ways, so every phase is TWO launches over all rectangles that are still undecided:
-//   k_lsd_nfa_count<PH>  wave = (rectangle, trial): the pixel scan (for the finer-precision phases wave = rectangle, one scan
-//                        for all five tolerances) -> (n, k) per trial;
-//   k_lsd_nfa_eval<PH>   THREAD = (rectangle, trial): nfa(n, k, p) is scalar code - thousands of independent evaluations
-//                        per launch instead of one per wave - drawn from a shared counter, because their lengths differ widely;
+//   k_lsd_nfa_count<PH>  16 lanes = (rectangle, trial): the pixel scan (for the finer-precision phases 16 lanes = rectangle, one
+//                        scan for all five tolerances) -> (n, k) per trial;
+//   k_lsd_nfa_setup<PH> / k_lsd_nfa_series<PH>  THREAD = (rectangle, trial): nfa(n, k, p) is scalar code - thousands of
+//                        independent evaluations per launch instead of one per wave; the series are drawn from a shared
+//                        counter, because their lengths differ widely;
 //   k_lsd_nfa_select<PH> thread = rectangle: the reference's sequential `if (v > log_nfa)` selection over the trials, the
 //                        chosen trial rebuilt by replaying its steps, accept / keep going / reject.
 // State per rectangle: PSL_LSD_RECT_F64 doubles in `rects` (x1 y1 x2 y2 width theta dx dy | prec p log_nfa) and one byte in
@@ -298,14 +343,17 @@ __device__ __forceinline__ void lsdn_load(const double* __restrict__ r, LsdnRect
     rec->prec = r[8]; rec->p = r[9];
 }
 
+#define PSL_NFA_GL 16   // lanes per pixel scan: four (rectangle, trial) scans per wave
 template <int PH>
 __global__ __launch_bounds__(256, 4) void k_lsd_nfa_count(LineParams P, const float* __restrict__ angdeg, double* __restrict__ rects,
                                                           const int* __restrict__ nrect, const uint8_t* __restrict__ keep, int2* __restrict__ counts) {
-    constexpr int TR = (PH >= 0 && PH <= 2) ? 5 : 1;   // waves per rectangle
-    const int frame = blockIdx.y, lane = threadIdx.x & 63;
+    constexpr int TR = (PH >= 0 && PH <= 2) ? 5 : 1;   // scans per rectangle
+    constexpr int GPB = 256 / PSL_NFA_GL;               // scans in flight per workgroup
+    const int frame = blockIdx.y, lane = threadIdx.x & (PSL_NFA_GL - 1);
     const int cnt = nrect[frame] < P.maxseg ? nrect[frame] : P.maxseg;
     const float* ang = angdeg + (size_t)frame * P.W * P.H;
-    for (int item = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6); item < cnt * TR; item += (int)gridDim.x * 4) {
+    // every lane runs its own trip count (its group's items); nothing inside the loop crosses groups
+    for (int item = (int)blockIdx.x * GPB + (int)(threadIdx.x / PSL_NFA_GL); item < cnt * TR; item += (int)gridDim.x * GPB) {
         const int idx = item / TR, j = item - idx * TR;
         const size_t o = (size_t)frame * P.maxseg + idx;
         if (PH != PSL_NFA_FIRST && keep[o] != 2) continue;
@@ -328,7 +376,7 @@ __global__ __launch_bounds__(256, 4) void k_lsd_nfa_count(LineParams P, const fl
             for (int t = 0; t < 5; ++t) { pp = pp / 2; pr[t] = PSL_DMUL(pp, PSL_PI); }
             int tot, kk[5];
             lsdn_geom(rec, P.H, &G);
-            lsdn_count<5>(ang, P.W, G, rec.theta, pr, lane, &tot, kk);
+            lsdn_count<5, PSL_NFA_GL>(ang, P.W, G, rec.theta, pr, lane, &tot, kk);
             if (lane == 0) {
 #pragma unroll
                 for (int t = 0; t < 5; ++t) out[t] = make_int2(tot, kk[t]);
@@ -344,78 +392,175 @@ __global__ __launch_bounds__(256, 4) void k_lsd_nfa_count(LineParams P, const fl
             int nn = -1, kk = 0;
             if (valid) {
                 lsdn_geom(rec, P.H, &G);
-                lsdn_count<1>(ang, P.W, G, rec.theta, &rec.prec, lane, &nn, &kk);
+                lsdn_count<1, PSL_NFA_GL>(ang, P.W, G, rec.theta, &rec.prec, lane, &nn, &kk);
             }
             if (lane == 0) out[j] = make_int2(nn, kk);
         }
     }
 }
 
-// nfa() for every (rectangle, trial) of a frame: THREAD = evaluation, scheduled dynamically.  The binomial tail of nfa() runs
-// for 1 .. ~900 iterations (mean ~40, heavy tail), so a wave that gives every lane ONE evaluation waits for its slowest lane
-// (measured: 10x the mean).  Here the lanes of a workgroup draw evaluations from a shared counter: a lane whose series has
-// stopped idles at most 15 iterations, until the next refill point, where all such lanes finish (log10, store), draw the next
-// item and set it up (three table loads, an exp) together - the hot loop between refill points is only the recurrence, the
-// division and the f32 pre-test.  Results overwrite the (n, k) pair of the trial with the value (a double, -inf for a trial
-// the width guard excludes); k_lsd_nfa_select reads them.
+// nfa() for every (rectangle, trial) of a frame, THREAD = evaluation, in two launches because its two halves behave differently:
+//   k_lsd_nfa_setup   everything before the binomial tail - the trivial cases, log_gamma from the table, the first term (an
+//                     exp) - uniform work, one item per thread; leaves either the value or the series' start (term, p_term);
+//                     and lists the frame's series by predicted length;
+//   k_lsd_nfa_series  the tail itself, 1 .. thousands of iterations per evaluation (mean ~40, heavy tail): a wave that mixes
+//                     lengths waits for its slowest lane, so a workgroup sums the series of ONE length class of several frames
+//                     (see the kernel).  -log10(sum) - logNT is left to k_lsd_nfa_select.
+// sstate[item] = (term, p_term), term == 0: no series (the value is in vals[item]; -inf for a trial the width guard excludes);
+// after the series: sstate[item].x = the binomial tail.
+struct LsdnSeries { double term, p_term; int n, i; unsigned slot, pad; };   // 32 B: one binomial tail to be summed
+#define PSL_NFA_NCLS 12   // length classes of the series: class c holds predicted lengths in [2^c, 2^(c+1)) (c = 11: all longer ones)
+#define PSL_NFA_FG 16     // frames whose series of one class are summed by one workgroup
+
+// predicted number of terms of the tail of B(n, p) from k + 1: the climb to the mode n p (if k is below it) plus a few standard
+// deviations, never more than n - k.  Only a scheduling hint: series of similar predicted length share a wave.
+__device__ __forceinline__ int lsdn_series_class(int n, int k, double p) {
+    const float np = (float)n * (float)p;
+    float len = fmaxf(0.0f, np - (float)k) + 4.0f * __builtin_sqrtf(np * (1.0f - (float)p)) + 4.0f;
+    len = fminf(len, (float)(n - k));
+    const int c = 31 - __clz((int)len | 1);
+    return c < PSL_NFA_NCLS - 1 ? c : PSL_NFA_NCLS - 1;
+}
+
+// workgroup = frame (all items of the frame, so that its series can be bucketed by predicted length in LDS without global
+// atomics).  list: [F][maxseg * 5] entries, class-major; coff: [F][PSL_NFA_NCLS + 1] offsets of the classes
 template <int PH>
-__global__ __launch_bounds__(256) void k_lsd_nfa_eval(LineParams P, LsdnTables T, const double* __restrict__ rects, const int* __restrict__ nrect,
-                                                      const uint8_t* __restrict__ keep, int2* __restrict__ counts) {
-    __shared__ int s_next;
-    const int frame = blockIdx.y;
+__global__ __launch_bounds__(256) void k_lsd_nfa_setup(LineParams P, LsdnTables T, const double* __restrict__ rects, const int* __restrict__ nrect,
+                                                       const uint8_t* __restrict__ keep, const int2* __restrict__ counts, double* __restrict__ vals,
+                                                       double2* __restrict__ sstate, LsdnSeries* __restrict__ tmp, LsdnSeries* __restrict__ list,
+                                                       int* __restrict__ coff) {
+    __shared__ int s_hist[PSL_NFA_NCLS], s_cur[PSL_NFA_NCLS];
+    const int frame = blockIdx.x, tid = threadIdx.x;
     const int cnt = nrect[frame] < P.maxseg ? nrect[frame] : P.maxseg;
     constexpr int TR = PH == PSL_NFA_FIRST ? 1 : 5;
-    const int nitems = cnt * TR;
-    const int per = (nitems + (int)gridDim.x - 1) / (int)gridDim.x;
-    const int begin = (int)blockIdx.x * per, end = min(begin + per, nitems);
-    if (begin >= end) return;
-    if (threadIdx.x == 0) s_next = begin;
-    __syncthreads();
     const double log_nt = T.log_nt;
-    double* vals = reinterpret_cast<double*>(counts);
-    // lane state
-    bool running = false, done = false;   // done: the series has stopped, the value is still to be written
-    int n = 0, i = 0;
-    size_t slot = 0;
-    double term = 0, bin_tail = 0, p_term = 0;
-    for (int iter = 0;; ++iter) {
-        if ((iter & 15) == 0) {   // refill point
-            if (done) { vals[slot] = PSL_DSUB(-psl_log10(bin_tail), log_nt); done = false; }
-            for (int tries = 0; tries < 1 && !running; ++tries) {
-                const int item = atomicAdd(&s_next, 1);
-                if (item >= end) break;
-                const int idx = item / TR, j = item - idx * TR;
-                const size_t o = (size_t)frame * P.maxseg + idx;
-                if (PH != PSL_NFA_FIRST && keep[o] != 2) continue;
-                slot = o * 5 + j;
-                const int2 c = counts[slot];
-                if (c.x < 0) { vals[slot] = -__builtin_inf(); continue; }
+    const int lcap = P.maxseg * 5;
+    LsdnSeries* TMP = tmp + (size_t)frame * lcap;
+    LsdnSeries* L = list + (size_t)frame * lcap;
+    if (tid < PSL_NFA_NCLS) s_hist[tid] = 0;
+    __syncthreads();
+    for (int item = tid; item < cnt * TR; item += 256) {
+        const int idx = item / TR, j = item - idx * TR;
+        const size_t o = (size_t)frame * P.maxseg + idx;
+        LsdnSeries e;
+        e.pad = 0xffffffffu;   // no series
+        if (PH == PSL_NFA_FIRST || keep[o] == 2) {
+            const size_t slot = o * 5 + j;
+            double v = 0, term = 0, p_term = 0;
+            const int2 c = counts[slot];
+            if (c.x < 0) v = -__builtin_inf();
+            else {
                 double p = rects[o * PSL_LSD_RECT_F64 + 9];
                 if (PH == -1 || PH == 3) for (int t = 0; t <= j; ++t) p = p / 2;
-                // nfa(): everything before the series
-                n = c.x;
-                const int k = c.y;
-                if (n == 0 || k == 0) { vals[slot] = -log_nt; continue; }
+                const int n = c.x, k = c.y;
+                // p = p0 / 2^jp: the table row, or -1 (a probability rect_improve cannot produce: evaluated directly)
                 int jp = (int)((__double_as_longlong(T.p0) >> 52) & 0x7ff) - (int)((__double_as_longlong(p) >> 52) & 0x7ff);
                 if (jp < 0 || jp >= PSL_NFA_NP || __longlong_as_double(__double_as_longlong(T.p0) - ((long long)jp << 52)) != p) jp = -1;
-                if (n == k) { vals[slot] = PSL_DSUB(-log_nt, PSL_DMUL((double)n, jp >= 0 ? T.logs[2 * PSL_NFA_NP + jp] : psl_log10(p))); continue; }
-                p_term = p / PSL_DSUB(1.0, p);
-                double log1term = PSL_DSUB(PSL_DSUB(lsdn_lg(T, n + 1), lsdn_lg(T, k + 1)), lsdn_lg(T, n - k + 1));
-                log1term = PSL_DADD(PSL_DADD(log1term, PSL_DMUL((double)k, jp >= 0 ? T.logs[jp] : psl_log(p))),
-                                    PSL_DMUL((double)(n - k), jp >= 0 ? T.logs[PSL_NFA_NP + jp] : psl_log(PSL_DSUB(1.0, p))));
-                term = psl_exp(log1term);
-                if (lsdn_double_equal0(term)) {
-                    vals[slot] = (double)k > PSL_DMUL((double)n, p) ? PSL_DSUB(-log1term / 2.30258509299404568402, log_nt) : -log_nt;
-                    continue;
+                if (n == 0 || k == 0) v = -log_nt;
+                else if (n == k) v = PSL_DSUB(-log_nt, PSL_DMUL((double)n, jp >= 0 ? T.logs[2 * PSL_NFA_NP + jp] : psl_log10(p)));
+                else {
+                    p_term = p / PSL_DSUB(1.0, p);
+                    double log1term = PSL_DSUB(PSL_DSUB(lsdn_lg(T, n + 1), lsdn_lg(T, k + 1)), lsdn_lg(T, n - k + 1));
+                    log1term = PSL_DADD(PSL_DADD(log1term, PSL_DMUL((double)k, jp >= 0 ? T.logs[jp] : psl_log(p))),
+                                        PSL_DMUL((double)(n - k), jp >= 0 ? T.logs[PSL_NFA_NP + jp] : psl_log(PSL_DSUB(1.0, p))));
+                    term = psl_exp(log1term);
+                    if (lsdn_double_equal0(term)) {
+                        v = (double)k > PSL_DMUL((double)n, p) ? PSL_DSUB(-log1term / 2.30258509299404568402, log_nt) : -log_nt;
+                        term = 0;
+                    } else {   // (k + 1 <= n here: the series has at least one term)
+                        e.term = term; e.p_term = p_term; e.n = n; e.i = k + 1; e.slot = (unsigned)(slot - (size_t)frame * lcap);
+                        e.pad = (unsigned)lsdn_series_class(n, k, p);
+                        atomicAdd(&s_hist[e.pad], 1);
+                    }
                 }
-                bin_tail = term;
-                i = k + 1;
-                if (i > n) { vals[slot] = PSL_DSUB(-psl_log10(bin_tail), log_nt); continue; }
-                running = true;
             }
-            if (!__syncthreads_or(running ? 1 : 0)) break;   // nobody in the workgroup has work left (the counter is exhausted)
+            vals[slot] = v;
+            sstate[slot] = make_double2(term, p_term);
         }
-        if (running) {   // one term of the binomial tail
+        TMP[item] = e;
+    }
+    __syncthreads();
+    if (tid == 0) {   // classes in DESCENDING length order: the longest series are listed (and started) first
+        int run = 0;
+        for (int c = PSL_NFA_NCLS - 1; c >= 0; --c) { s_cur[c] = run; coff[frame * (PSL_NFA_NCLS + 1) + (PSL_NFA_NCLS - 1 - c)] = run; run += s_hist[c]; }
+        coff[frame * (PSL_NFA_NCLS + 1) + PSL_NFA_NCLS] = run;
+    }
+    __syncthreads();
+    for (int item = tid; item < cnt * TR; item += 256) {
+        const LsdnSeries e = TMP[item];
+        if (e.pad != 0xffffffffu) L[atomicAdd(&s_cur[e.pad], 1)] = e;
+    }
+}
+
+// The binomial tails, one per THREAD.  Workgroup = (length class, PSL_NFA_FG frames): the series of that class of those frames
+// are dealt to its threads round-robin, so the lanes of a wave sum series of similar length (a wave that mixes lengths waits
+// for its longest: measured 7 % lane use with one workgroup per frame).  A thread works through its entries one after the
+// other and has the next one loaded before it needs it; a lane whose series has stopped idles until an eighth of its wave is
+// idle - then all such lanes store their sums and start their next entries together.  The hot loop between two such points is
+// the recurrence, the division and the pre-test.
+template <int PH>
+__global__ __launch_bounds__(256) void k_lsd_nfa_series(LineParams P, LsdnTables T, int nframes, const LsdnSeries* __restrict__ list,
+                                                        const int* __restrict__ coff, double2* __restrict__ sstate) {
+    __shared__ int s_begin[PSL_NFA_FG], s_pref[PSL_NFA_FG + 1];
+    const int cls = blockIdx.x, f0 = (int)blockIdx.y * PSL_NFA_FG, tid = threadIdx.x;
+    const int lcap = P.maxseg * 5;
+    if (tid == 0) {
+        int run = 0;
+        for (int f = 0; f < PSL_NFA_FG; ++f) {
+            int b = 0, c = 0;
+            if (f0 + f < nframes) { b = coff[(f0 + f) * (PSL_NFA_NCLS + 1) + cls]; c = coff[(f0 + f) * (PSL_NFA_NCLS + 1) + cls + 1] - b; }
+            s_begin[f] = b; s_pref[f] = run; run += c;
+        }
+        s_pref[PSL_NFA_FG] = run;
+    }
+    __syncthreads();
+    const int total = s_pref[PSL_NFA_FG];
+    if (total == 0) return;
+    // virtual index t in the concatenation of the frames' class segments -> the entry and its frame
+    auto locate = [&](int t, int* fr) {
+        int f = 0;
+#pragma unroll
+        for (int g = 1; g < PSL_NFA_FG; ++g) f += t >= s_pref[g] ? 1 : 0;
+        *fr = f;
+        return list + (size_t)(f0 + f) * lcap + s_begin[f] + (t - s_pref[f]);
+    };
+    const double log_nt = T.log_nt;
+    bool running = false, done = false;
+    int mine = tid;
+    bool have_next = mine < total;
+    LsdnSeries nxt = {};
+    int nxt_f = 0;
+    if (have_next) nxt = *locate(mine, &nxt_f);
+    int n = 0, i = 0;
+    double2* out = nullptr;
+    double term = 0, bin_tail = 0, p_term = 0;
+    for (;;) {
+        if (__popcll(__ballot(!running)) >= 8) {
+            if (done) { out->x = bin_tail; done = false; }
+            if (!running && have_next) {
+                n = nxt.n; i = nxt.i; term = nxt.term; bin_tail = nxt.term; p_term = nxt.p_term;
+                out = sstate + (size_t)(f0 + nxt_f) * lcap + nxt.slot;
+                running = true;
+                mine += 256;
+                have_next = mine < total;
+                if (have_next) nxt = *locate(mine, &nxt_f);   // in flight while this series runs
+            }
+            if (!__ballot(running)) break;
+        }
+        if (running && i + 7 <= n && 2 * (i + 7) <= n + 1) {
+            // eight terms at once while bin_term >= 1 (i <= (n + 1) / 2: the reference does not test there - 98 % of all terms): the
+            // divisions are independent of the running product, only the multiply-add chain is serial
+            double bt[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) bt[u] = (double)(n - i - u + 1) / (double)(i + u);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                term = PSL_DMUL(term, PSL_DMUL(bt[u], p_term));
+                bin_tail = PSL_DADD(bin_tail, term);
+            }
+            i += 8;
+            if (i > n) { running = false; done = true; }
+        } else if (running) {   // one term of the binomial tail
             const double bin_term = (double)(n - i + 1) / (double)i;
             const double mult_term = PSL_DMUL(bin_term, p_term);
             term = PSL_DMUL(term, mult_term);
@@ -440,11 +585,11 @@ __global__ __launch_bounds__(256) void k_lsd_nfa_eval(LineParams P, LsdnTables T
 // thread = rectangle: the reference's selection over the trials of the phase, in trial order - `if (v > log_nfa) { log_nfa = v;
 // rec = r; }` - the chosen trial rebuilt by replaying its steps, and the verdict if there is one
 template <int PH>
-__global__ __launch_bounds__(256) void k_lsd_nfa_select(LineParams P, double* __restrict__ rects, const int* __restrict__ nrect,
-                                                        uint8_t* __restrict__ keep, const int2* __restrict__ counts, float* __restrict__ segtmp) {
+__global__ __launch_bounds__(256) void k_lsd_nfa_select(LineParams P, double log_nt, double* __restrict__ rects, const int* __restrict__ nrect,
+                                                        uint8_t* __restrict__ keep, const double* __restrict__ vals, const double2* __restrict__ sstate,
+                                                        float* __restrict__ segtmp) {
     const int frame = blockIdx.y;
     const int cnt = nrect[frame] < P.maxseg ? nrect[frame] : P.maxseg;
-    const double* vals = reinterpret_cast<const double*>(counts);
     for (int idx = (int)(blockIdx.x * 256 + threadIdx.x); idx < cnt; idx += (int)gridDim.x * 256) {
         const size_t o = (size_t)frame * P.maxseg + idx;
         if (PH != PSL_NFA_FIRST && keep[o] != 2) continue;
@@ -453,12 +598,17 @@ __global__ __launch_bounds__(256) void k_lsd_nfa_select(LineParams P, double* __
         lsdn_load(rs, &rec);
         double logn;
         int best = -1;
-        if (PH == PSL_NFA_FIRST) logn = vals[o * 5];
+        // nfa() of trial t: the value k_lsd_nfa_setup left, or -log10(binomial tail) - logNT of its series
+        auto value = [&](int t) {
+            const double bt = sstate[o * 5 + t].x;
+            return bt != 0 ? PSL_DSUB(-psl_log10(bt), log_nt) : vals[o * 5 + t];
+        };
+        if (PH == PSL_NFA_FIRST) logn = value(0);
         else {
             logn = rs[10];
-#pragma unroll
+#pragma unroll 1
             for (int t = 0; t < 5; ++t) {
-                const double vt = vals[o * 5 + t];
+                const double vt = value(t);
                 if (vt > logn) { logn = vt; best = t; }
             }
         }

@@ -39,6 +39,11 @@ struct pslfe_line {
     float* d_segtmp = nullptr;
     uint8_t* d_keep = nullptr;
     int2* d_counts = nullptr;     // (n, k) of the five trial rectangles of a rect_improve phase
+    double* d_vals = nullptr;     // their nfa() values
+    double2* d_sstate = nullptr;  // (first term, p / (1 - p)) of the binomial tails that have to be summed
+    LsdnSeries* d_slist = nullptr;  // ... as one list per frame, by predicted length (d_stmp: in item order, before the bucketing)
+    LsdnSeries* d_stmp = nullptr;
+    int* d_lcount = nullptr;        // class offsets in the list, [F][PSL_NFA_NCLS + 1]
     float* d_seg = nullptr;
     int* d_nseg = nullptr;
     MergeScratch M = {};
@@ -65,8 +70,8 @@ struct pslfe_line {
         hipFree(d_trig); d_trig = nullptr;
         hipFree(d_seedt); d_seedt = nullptr;
         hipFree(d_in); hipFree(d_scaled); hipFree(d_angdeg); hipFree(d_modgrad); hipFree(d_reg);
-        hipFree(d_seg); hipFree(d_nseg); hipFree(d_rects); hipFree(d_nrect); hipFree(d_segtmp); hipFree(d_keep); hipFree(d_lgamma); hipFree(d_counts);
-        d_counts = nullptr;
+        hipFree(d_seg); hipFree(d_nseg); hipFree(d_rects); hipFree(d_nrect); hipFree(d_segtmp); hipFree(d_keep); hipFree(d_lgamma); hipFree(d_counts); hipFree(d_vals); hipFree(d_sstate); hipFree(d_slist); hipFree(d_stmp); hipFree(d_lcount);
+        d_counts = nullptr; d_vals = nullptr; d_sstate = nullptr; d_slist = nullptr; d_stmp = nullptr; d_lcount = nullptr;
         d_lgamma = nullptr;
         d_in = nullptr; d_scaled = nullptr; d_angdeg = nullptr; d_modgrad = nullptr; d_reg = nullptr;
         d_seg = nullptr; d_nseg = nullptr; d_rects = nullptr; d_nrect = nullptr; d_segtmp = nullptr; d_keep = nullptr;
@@ -157,6 +162,11 @@ struct pslfe_line {
         PSL_ALLOC(d_segtmp, (size_t)Q.maxseg * 4 * sizeof(float) * F);
         PSL_ALLOC(d_keep, (size_t)Q.maxseg * F);
         PSL_ALLOC(d_counts, (size_t)Q.maxseg * 5 * sizeof(int2) * F);
+        PSL_ALLOC(d_vals, (size_t)Q.maxseg * 5 * sizeof(double) * F);
+        PSL_ALLOC(d_sstate, (size_t)Q.maxseg * 5 * sizeof(double2) * F);
+        PSL_ALLOC(d_slist, (size_t)Q.maxseg * 5 * sizeof(LsdnSeries) * F);
+        PSL_ALLOC(d_stmp, (size_t)Q.maxseg * 5 * sizeof(LsdnSeries) * F);
+        PSL_ALLOC(d_lcount, F * (PSL_NFA_NCLS + 1) * sizeof(int));
         {   // nfa() tables: the same functions the device would evaluate, here on the host (bit-identical: single IEEE operations)
             const int lgn = 1 << 16;
             std::vector<double> lg((size_t)lgn, 0.0);
@@ -235,11 +245,11 @@ struct pslfe_line {
             PSL_STAGE_END(ctx, "line.lsd_grow");
         }
         if (refine >= 2) {
-            // rect_improve + NFA: per phase a pixel-scan launch (wave = rectangle x trial), an nfa() launch (thread = evaluation) and a
-            // selection launch (thread = rectangle), line_kernels3.h.  A few hundred rectangles per frame: a many-frames launch fills
+            // rect_improve + NFA: per phase a pixel-scan launch (16 lanes = rectangle x trial), two nfa() launches (thread = evaluation:
+            // set-up, then the binomial tails drawn from a shared counter) and a selection launch (thread = rectangle), line_kernels3.h.  A few hundred rectangles per frame: a many-frames launch fills
             // the chip by frames, a single frame by chunks.  (The stage timers record the launches of a phase as they are issued;
             // with profiling on, every stage costs two event records.)
-            const dim3 gc(F >= 64 ? 8 : 128, F), ge(F >= 64 ? 1 : 8, F), gs(F >= 64 ? 1 : 4, F);
+            const dim3 gc(F >= 64 ? 8 : 128, F), gs(F >= 64 ? 1 : 4, F);
 #define PSL_NFA_PHASE(PH)                                                                                                \
     {                                                                                                                    \
         PSL_STAGE_BEGIN(ctx, "line.nfa_count");                                                                          \
@@ -248,8 +258,9 @@ struct pslfe_line {
     }                                                                                                                    \
     {                                                                                                                    \
         PSL_STAGE_BEGIN(ctx, "line.nfa_eval");                                                                           \
-        k_lsd_nfa_eval<PH><<<ge, 256, 0, st>>>(P, NT, d_rects, d_nrect, d_keep, d_counts);                              \
-        k_lsd_nfa_select<PH><<<gs, 256, 0, st>>>(P, d_rects, d_nrect, d_keep, d_counts, d_segtmp);                      \
+        k_lsd_nfa_setup<PH><<<F, 256, 0, st>>>(P, NT, d_rects, d_nrect, d_keep, d_counts, d_vals, d_sstate, d_stmp, d_slist, d_lcount); \
+        k_lsd_nfa_series<PH><<<dim3(PSL_NFA_NCLS, (F + PSL_NFA_FG - 1) / PSL_NFA_FG), 256, 0, st>>>(P, NT, (int)F, d_slist, d_lcount, d_sstate); \
+        k_lsd_nfa_select<PH><<<gs, 256, 0, st>>>(P, NT.log_nt, d_rects, d_nrect, d_keep, d_vals, d_sstate, d_segtmp);           \
         PSL_STAGE_END(ctx, "line.nfa_eval");                                                                             \
     }
             PSL_NFA_PHASE(PSL_NFA_FIRST)
