@@ -242,6 +242,9 @@ def main():
     ap.add_argument("--workload", choices=["orb", "lines", "dropin", "tracking"], default="lines",
                     help="lines = BASELINE configs[2], the configuration of the headline metric; orb = configs[1]; dropin = B = 1 through the "
                          "C++ consumer; tracking = configs[4] through the C++ consumer")
+    ap.add_argument("--streams", type=int, default=1, choices=[1, 2],
+                    help="2: the line pipeline on its own context / stream beside the ORB pipeline (the two extractor objects of a Frame are "
+                         "independent); stages then overlap and their event timings stop meaning what they say, so 1 is the default")
     ap.add_argument("--host-io", action="store_true", help="host gray + depth in, host result records out, inside the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--parity-frames", type=int, default=8)
@@ -290,7 +293,8 @@ def main():
     # torch.cuda events / synchronize see everything
     stream = torch.cuda.Stream(dev)
     torch.cuda.set_stream(stream)
-    pipe = BP.BatchPipeline(P, torch, dev, stream, local_rank, B, W, H, lines=LINES)
+    stream_l = torch.cuda.Stream(dev) if (args.streams == 2 and LINES) else None
+    pipe = BP.BatchPipeline(P, torch, dev, stream, local_rank, B, W, H, lines=LINES, second_stream=stream_l)
     ctx = pipe.ctx
 
     # the batch: B frames = the 256 distinct frames repeated; depth (lines): the scene's plane, f32 metres
@@ -320,7 +324,11 @@ def main():
                 P._check(P.lib().pslfe_depth_to_float_device(ctx._h, __import__("ctypes").c_void_p(host_io["d_depth16"].data_ptr()),
                                                              __import__("ctypes").c_size_t(B * H * W), __import__("ctypes").c_float(1.0 / 5000.0),
                                                              __import__("ctypes").c_void_p(depth_d.data_ptr())), "pslfe_depth_to_float_device")
+        if stream_l is not None:
+            stream_l.wait_stream(stream)     # the inputs (and the previous step's record pack) are ordered on the main stream
         pipe.step(frames_d.data_ptr(), depth_d.data_ptr() if LINES else None)
+        if stream_l is not None:
+            stream.wait_stream(stream_l)     # join: the step ends when both pipelines have
         if gather is not None:
             k = gather.submit(pipe.record_sources(mg))
             if rec_host is not None:   # D2H of this rank's packed records inside the step
@@ -442,7 +450,7 @@ def main():
                                    ("configs[1]: 640x480 synthetic RGB-D stream (desk-like), ORB 1000/1.2/8 FAST 20/7 "
                                     "extract + SearchByProjection(cur,last) match, " + io),
                        "frames_per_step_per_gpu": B, "distinct_frames_per_batch": int(min(B, ND)), "mean_keypoints": round(mean_kp, 1),
-                       "mean_matches": round(mean_matches, 1), "host_io": bool(args.host_io),
+                       "mean_matches": round(mean_matches, 1), "host_io": bool(args.host_io), "streams": args.streams,
                        "multi_gpu": ("independent stream per rank; per-frame result records (counts, keypoints, descriptors, point matches, keylines, LBD "
                                      "descriptors, line equations, line matches, fans, planes) packed and all-gathered with RCCL through the C ABI "
                                      f"(pslfe_gather_all), {layout.bytes} B per frame") if world > 1 else "single GPU"},

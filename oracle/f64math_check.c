@@ -3,8 +3,8 @@
  *   log, exp, log10 : dense samples of the ranges nfa() / log_gamma() use; reports the largest difference in ulps
  *            and the share of samples that differ at all (glibc's own algorithms are table-driven and not reproducible
  *            offline: the contract is "within 1 ulp").
- *   sincos : psl_cos_sin_f64 (psl_sincos64.h) on [-pi/2, pi/2], the range of MergeTwoLines' `thr`
- *            (add_src/uselongline.cpp:320-329): largest difference in ulps against libm's sin / cos.
+ *   sincos : psl_glibc_sin / psl_glibc_cos (psl_sincos_glibc.h) on [-pi/2, pi/2] (MergeTwoLines' `thr`,
+ *            add_src/uselongline.cpp:320-329), [0, 9.5] (region2rect's theta) and [-1000, 1000]: bit-identical to libm.
  * usage: f64math_check tanf [lo_bits hi_bits] | f64 [nsamples] | sincos [nsamples]
  * build: gcc -O2 -ffp-contract=off -mfma -o f64math_check f64math_check.c -lm -lpthread */
 #include <math.h>
@@ -18,6 +18,10 @@
 #include "../psl-slam_amd/csrc/psl_f64math.h"
 #define PSL_SC64_QUAL static inline
 #include "../psl-slam_amd/csrc/psl_sincos64.h"
+#include "../psl-slam_amd/csrc/psl_sincos_glibc.h"
+static const double SCTAB[444] = {
+#include "../psl-slam_amd/csrc/psl_sincostab.inc"
+};
 
 #define NT 8
 static uint32_t g_lo, g_hi;
@@ -64,18 +68,19 @@ int main(int argc, char** argv) {
         printf("tanf floats %llu mismatches %llu first 0x%08x\n", (unsigned long long)g_hi - g_lo + 1, bad, first);
         return bad ? 1 : 0;
     }
-    if (!strcmp(argv[1], "sincos")) {
-        const long n = argc > 2 ? atol(argv[2]) : 4000000;
-        int64_t ms = 0, mc = 0; long ds = 0, dc = 0;
-        for (long i = 0; i < n; ++i) {
-            const double x = (urand() - 0.5) * 3.14159265358979323846;
-            double c, s2;
-            psl_cos_sin_f64(x, &c, &s2);
-            int64_t d = ulps(sin(x), s2); if (d) ++ds; if (d > ms) ms = d;
-            d = ulps(cos(x), c); if (d) ++dc; if (d > mc) mc = d;
-        }
-        printf("sincos samples %ld sin max_ulp %lld differ %ld cos max_ulp %lld differ %ld\n", n, (long long)ms, ds, (long long)mc, dc);
-        return (ms <= 2 && mc <= 2) ? 0 : 1;
+    if (!strcmp(argv[1], "sincos")) {   /* psl_glibc_sin / psl_glibc_cos must be bit-identical to libm */
+        const long n = argc > 2 ? atol(argv[2]) : 20000000;
+        const double ranges[3][2] = {{-1.5707963267948966, 1.5707963267948966}, {0.0, 9.5}, {-1000.0, 1000.0}};
+        long bad = 0;
+        for (int r = 0; r < 3; ++r)
+            for (long i = 0; i < n; ++i) {
+                double x = ranges[r][0] + (ranges[r][1] - ranges[r][0]) * urand();
+                if (i % 7 == 0) x *= 1e-4;   /* small arguments */
+                const double a = sin(x), b = psl_glibc_sin(x, SCTAB), c = cos(x), d = psl_glibc_cos(x, SCTAB);
+                if (memcmp(&a, &b, 8) || memcmp(&c, &d, 8)) { if (bad < 5) printf("x %a: sin %a vs %a, cos %a vs %a\n", x, a, b, c, d); ++bad; }
+            }
+        printf("sincos samples %ld mismatches %ld\n", 3 * n, bad);
+        return bad ? 1 : 0;
     }
     const long n = argc > 2 ? atol(argv[2]) : 4000000;
     int64_t mx[3] = {0, 0, 0}; long diff[3] = {0, 0, 0};

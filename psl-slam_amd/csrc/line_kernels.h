@@ -22,6 +22,7 @@
 #define PSL_LSD_NOTDEF (-1024.0f)   // angle map label for "gradient undefined" (stored as f32 degrees)
 #define PSL_SC64_QUAL __host__ __device__ static inline
 #include "psl_sincos64.h"
+#include "psl_sincos_glibc.h"
 #define PSL_F64_QUAL __host__ __device__ static inline
 #include "psl_f64math.h"
 #define PSL_PI 3.1415926535897932384626433832795
@@ -37,6 +38,7 @@ struct LineParams {
     double rho, prec, p;      // gradient threshold, angle tolerance (rad), p = ANG_TH/180
     double rho_q;             // largest q with sqrt(q) <= rho: `norm <= rho` decided on the squared magnitude
     int min_reg_size;
+    const double* sctab;      // psl_sincostab.inc in HBM: the table of the glibc-exact double sin / cos (psl_sincos_glibc.h)
     int refine;               // 1 = LSD_REFINE_STD (segments leave k_lsd_grow3), 2 = LSD_REFINE_ADV (rectangles -> k_lsd_nfa -> k_lsd_emit)
     double log_nt;            // LOG_NT of the NFA: 5 (log10 W + log10 H) / 2 + log10 11
     int full_grad;            // k_lsd_grad stores the gradient magnitude of every pixel (debug tap), not only where the angle is defined
@@ -341,6 +343,7 @@ struct LsdW {
     const double* mod;
     float4* trig;          // (cosf, sinf, degrees | NOTDEF, used flag) per pixel
     const float2* seedt;   // (float)cos, (float)sin of the double angle (seed pixels)
+    const double* sctab;
     uint32_t* ring;   // LDS mirror of reg[idx & (RING-1)]
     double* term;     // LDS [3][64]
     uint32_t* reg;    // HBM queue
@@ -575,8 +578,9 @@ __device__ void lsdw_region2rect(const LsdW& F, int reg_size, double reg_angle, 
                                            : (double)psl_fast_atan2((float)Ixy, (float)PSL_DSUB(lambda, Iyy));
     theta = PSL_DMUL(theta, PSL_DEG2RAD);
     if (fabs(psl_angle_diff_signed(theta, reg_angle)) > prec) theta = PSL_DADD(theta, PSL_PI);
-    double dx, dy;  // cos / sin of theta in [0, 3 pi): restricted-range evaluation (the general f64 pair costs ~250 instructions per
-    psl_cos_sin_f64(theta, &dx, &dy);  // rectangle on this serial path); the end points are rounded to f32 afterwards
+    // cos / sin of theta in [0, 3 pi) exactly as glibc's (psl_sincos_glibc.h): they feed the rectangle's f64 arithmetic, whose results
+    // are truncated to int by the NFA's pixel scan
+    const double dx = psl_glibc_cos(theta, F.sctab), dy = psl_glibc_sin(theta, F.sctab);
     double l_min = 0, l_max = 0, w_min = 0, w_max = 0;  // order-independent: max(0, max l), min(0, min l)
     for (int j = F.lane; j < reg_size; j += 64) {
         const uint32_t rp = lsdw_reg(F, j, reg_size);
@@ -699,7 +703,7 @@ __global__ __launch_bounds__(64, PSL_GROW_WAVES) void k_lsd_grow3(LineParams P, 
     LsdW F;
     F.W = P.W; F.H = P.H; F.lane = lane;
     F.ang = angdeg + frame * npx; F.mod = modgrad + frame * npx; F.trig = trig + frame * npx; F.reg = reg + frame * npx;
-    F.seedt = seedt + frame * npx; F.ring = s_ring; F.term = s_term;
+    F.seedt = seedt + frame * npx; F.ring = s_ring; F.term = s_term; F.sctab = P.sctab;
     // (the used flags start at 0: k_lsd_grad has just written the records)
     (void)words;
     float* out = seg + (size_t)frame * P.maxseg * 4;

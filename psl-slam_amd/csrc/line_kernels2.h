@@ -4,9 +4,8 @@
 // (atan, atan2, tan, sin, cos) are the float overloads; sinf/cosf are psl_sincosf (bit-identical to
 // glibc on [-2pi, 2pi]), atanf / atan2f are psl_atanf / psl_atan2f (glibc's float algorithms restated, pinned against libm);
 // tanf is psl_tanf (glibc's float tanf restated, bit-identical for every float in [0, 120), psl_f64math.h); the double sin / cos
-// of MergeTwoLines are psl_cos_sin_f64 (fdlibm kernels, psl_sincos64.h: within 1 ulp of glibc, whose own table-driven algorithm is
-// not reproducible offline - the merged end points are rounded to float, so a last-ulp difference shows only if the double result
-// lies within ~1e-16 relative of a float rounding boundary).  Nothing here calls the device math library.
+// of MergeTwoLines are glibc's table-driven algorithm restated with a regenerated table (psl_sincos_glibc.h, bit-identical to
+// libm on 6e7 arguments).  Nothing here calls the device math library.
 #ifndef PSL_LINE_KERNELS2_H
 #define PSL_LINE_KERNELS2_H
 
@@ -75,7 +74,7 @@ __device__ bool psl_merge_pair(const float* src, const float* angles, int idx1, 
     return to_merge;
 }
 
-__device__ void psl_merge_two_lines(const float* l1, const float* l2, float* out) {  // :266-334
+__device__ void psl_merge_two_lines(const float* l1, const float* l2, float* out, const double* sctab) {  // :266-334
     const float ax = l1[0], ay = l1[1], bx = l1[2], by = l1[3], cx = l2[0], cy = l2[1], dx = l2[2], dy = l2[3];
     const float dlix = PSL_FSUB(bx, ax), dliy = PSL_FSUB(by, ay), dljx = PSL_FSUB(dx, cx), dljy = PSL_FSUB(dy, cy);
     const double li = __dsqrt_rn(PSL_DADD((double)PSL_FMUL(dlix, dlix), (double)PSL_FMUL(dliy, dliy)));
@@ -92,8 +91,8 @@ __device__ void psl_merge_two_lines(const float* l1, const float* l2, float* out
         thr = PSL_DADD(PSL_DMUL(li, thi), PSL_DMUL(lj, tmp));
         thr = thr / PSL_DADD(li, lj);
     }
-    double s, c;  // thr in [-pi/2, pi/2]: restricted-range evaluation (psl_sincos64.h), pinned against libm in the CPU suite
-    psl_cos_sin_f64(thr, &c, &s);
+    // glibc's double sin / cos, bit for bit (psl_sincos_glibc.h): d1 * s + yg can cancel (an end point on the image border)
+    const double s = psl_glibc_sin(thr, sctab), c = psl_glibc_cos(thr, sctab);
     const double axg = PSL_DADD(PSL_DMUL(PSL_DSUB((double)ay, yg), s), PSL_DMUL(PSL_DSUB((double)ax, xg), c));
     const double bxg = PSL_DADD(PSL_DMUL(PSL_DSUB((double)by, yg), s), PSL_DMUL(PSL_DSUB((double)bx, xg), c));
     const double cxg = PSL_DADD(PSL_DMUL(PSL_DSUB((double)cy, yg), s), PSL_DMUL(PSL_DSUB((double)cx, xg), c));
@@ -143,7 +142,7 @@ __device__ __forceinline__ const uint32_t* psl_merge_row(MergeLds<LN>& LD, const
 
 template <int LN>
 __device__ int psl_merge_pass(const MergeScratch& M, MergeLds<LN>& LD, const float* src, float* dst, int n, float angle_threshold,
-                              float distance_threshold, float endpoint_threshold, float length_thr, int* s_i) {
+                              float distance_threshold, float endpoint_threshold, float length_thr, int* s_i, const double* sctab) {
     const int tid = threadIdx.x, BS = 256;
     if (n <= 0) return 0;
     const bool small = n <= LN;
@@ -434,7 +433,7 @@ __device__ int psl_merge_pass(const MergeScratch& M, MergeLds<LN>& LD, const flo
         float nl[4] = {src[4 * cl[0]], src[4 * cl[0] + 1], src[4 * cl[0] + 2], src[4 * cl[0] + 3]};
         for (int q = 0; q < cs; ++q) {
             float o[4];
-            psl_merge_two_lines(nl, &src[4 * cl[q]], o);
+            psl_merge_two_lines(nl, &src[4 * cl[q]], o, sctab);
             nl[0] = o[0]; nl[1] = o[1]; nl[2] = o[2]; nl[3] = o[3];
         }
         M.merged[4 * c] = nl[0]; M.merged[4 * c + 1] = nl[1]; M.merged[4 * c + 2] = nl[2]; M.merged[4 * c + 3] = nl[3];
@@ -511,8 +510,8 @@ __global__ __launch_bounds__(256, LN <= PSL_MERGE_LDSN_SMALL ? 8 : 5) void k_lin
     const float* src = seg + f * P.maxseg * 4;
     for (int i = tid; i < n * 4; i += 256) M.lines0[i] = src[i];
     __syncthreads();
-    n = psl_merge_pass(M, LD, M.lines0, M.lines1, n, 0.05f, 5.f, 15.f, 30.f, s_i);
-    n = psl_merge_pass(M, LD, M.lines1, M.lines0, n, 0.03f, 3.f, 30.f, 50.f, s_i);
+    n = psl_merge_pass(M, LD, M.lines0, M.lines1, n, 0.05f, 5.f, 15.f, 30.f, s_i, P.sctab);
+    n = psl_merge_pass(M, LD, M.lines1, M.lines0, n, 0.03f, 3.f, 30.f, 50.f, s_i, P.sctab);
     st |= s_i[1] << 1;
     // convertVec4fToKeyLine (:411-447)
     const float* L = M.lines0;

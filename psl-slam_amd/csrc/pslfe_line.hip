@@ -34,6 +34,7 @@ struct pslfe_line {
     uint32_t* d_reg = nullptr;
     LsdnTables NT = {};           // LSD_REFINE_ADV: log_gamma / log(p) tables of nfa() (NT.lg in HBM)
     double* d_lgamma = nullptr;
+    double* d_sctab = nullptr;    // psl_sincostab.inc
     double* d_rects = nullptr;    // LSD_REFINE_ADV: rectangles of k_lsd_grow3 for k_lsd_nfa
     int* d_nrect = nullptr;
     float* d_segtmp = nullptr;
@@ -70,7 +71,8 @@ struct pslfe_line {
         hipFree(d_trig); d_trig = nullptr;
         hipFree(d_seedt); d_seedt = nullptr;
         hipFree(d_in); hipFree(d_scaled); hipFree(d_angdeg); hipFree(d_modgrad); hipFree(d_reg);
-        hipFree(d_seg); hipFree(d_nseg); hipFree(d_rects); hipFree(d_nrect); hipFree(d_segtmp); hipFree(d_keep); hipFree(d_lgamma); hipFree(d_counts); hipFree(d_vals); hipFree(d_sstate); hipFree(d_slist); hipFree(d_stmp); hipFree(d_lcount);
+        hipFree(d_seg); hipFree(d_nseg); hipFree(d_rects); hipFree(d_nrect); hipFree(d_segtmp); hipFree(d_keep); hipFree(d_lgamma); hipFree(d_sctab);
+        d_sctab = nullptr; hipFree(d_counts); hipFree(d_vals); hipFree(d_sstate); hipFree(d_slist); hipFree(d_stmp); hipFree(d_lcount);
         d_counts = nullptr; d_vals = nullptr; d_sstate = nullptr; d_slist = nullptr; d_stmp = nullptr; d_lcount = nullptr;
         d_lgamma = nullptr;
         d_in = nullptr; d_scaled = nullptr; d_angdeg = nullptr; d_modgrad = nullptr; d_reg = nullptr;
@@ -167,6 +169,15 @@ struct pslfe_line {
         PSL_ALLOC(d_slist, (size_t)Q.maxseg * 5 * sizeof(LsdnSeries) * F);
         PSL_ALLOC(d_stmp, (size_t)Q.maxseg * 5 * sizeof(LsdnSeries) * F);
         PSL_ALLOC(d_lcount, F * (PSL_NFA_NCLS + 1) * sizeof(int));
+        {
+            static const double sctab[444] = {
+#include "psl_sincostab.inc"
+            };
+            PSL_ALLOC(d_sctab, sizeof(sctab));
+            const hipError_t e_ = hipMemcpy(d_sctab, sctab, sizeof(sctab), hipMemcpyHostToDevice);
+            if (e_ != hipSuccess) return fail_prepare(e_, "d_sctab (upload)");
+            Q.sctab = d_sctab;
+        }
         {   // nfa() tables: the same functions the device would evaluate, here on the host (bit-identical: single IEEE operations)
             const int lgn = 1 << 16;
             std::vector<double> lg((size_t)lgn, 0.0);

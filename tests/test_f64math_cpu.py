@@ -36,11 +36,19 @@ def test_restated_log_exp_log10_within_one_ulp_of_libm(check_exe):
     print(out.stdout.strip())
 
 
-def test_restricted_range_sin_cos_within_two_ulp_of_libm(check_exe):
-    """MergeTwoLines' double sin / cos of thr in [-pi/2, pi/2] (add_src/uselongline.cpp:320-329): psl_cos_sin_f64."""
-    out = subprocess.run([check_exe, "sincos", "4000000"], capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0, out.stdout
-    print(out.stdout.strip())
+def test_restated_double_sin_cos_equal_libm(check_exe):
+    """MergeTwoLines' double sin / cos of thr in [-pi/2, pi/2] (add_src/uselongline.cpp:320-329) and region2rect's cos / sin of
+    theta in [0, 3 pi): glibc's table-driven algorithm restated with a table regenerated from the series
+    (psl-slam_amd/csrc/psl_sincos_glibc.h, tools/gen_sincostab.py).  Bit-identical to this host's libm on 3 x 2e7 arguments."""
+    out = subprocess.run([check_exe, "sincos", "20000000"], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "mismatches 0" in out.stdout, out.stdout
+
+
+def test_sincos_table_is_what_the_generator_writes(tmp_path):
+    inc = os.path.join(ROOT, "psl-slam_amd", "csrc", "psl_sincostab.inc")
+    before = open(inc).read()
+    subprocess.run(["python", os.path.join(ROOT, "tools", "gen_sincostab.py")], check=True, capture_output=True)
+    assert open(inc).read() == before
 
 
 # ---- nfa(): plain-Python restatement of OpenCV 3.x lsd.cpp (twin: Thirdparty/line_descriptor/src/ED_Lib/NFA.cpp:106-240)

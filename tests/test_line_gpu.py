@@ -78,6 +78,30 @@ def test_lsd_segments(style, seed, refine_mode):
     assert exact
 
 
+@pytest.mark.parametrize("refine_mode", [ADV, STD], indirect=True)
+def test_line_stages_at_1280x960(refine_mode):
+    """BASELINE configs[4]'s geometry (LSD on 1024x768): gradient stage, segment list, merge, LBD, pairing and the whole extractor,
+    bit for bit."""
+    import oracle_lib
+    img = _scene("struct", 41, 0, 1280, 960)
+    le = _extractor(refine_mode, 1, 1.2, 200, 0.0)
+    seg = le.lsd_detect(img)
+    ref_seg = oracle_lib.lsd_detect(img)
+    assert len(ref_seg) > (200 if refine_mode == STD else 100) and seg.shape == ref_seg.shape and (seg.view(np.uint32) == ref_seg.view(np.uint32)).all()
+    scaled, angdeg, mod = le.debug_gradient(0)
+    rs, ra, rm = oracle_lib.lsd_gradient(img)
+    np.testing.assert_array_equal(scaled, rs)
+    gang = np.where(angdeg == -1024.0, -1024.0, angdeg.astype(np.float64) * DEG2RAD)
+    np.testing.assert_array_equal(gang, ra)
+    _kl_equal(le.optimize_and_merge(ref_seg, 1280, 960, cap=4096), oracle_lib.optimize_and_merge(ref_seg, 1280, 960, cap=4096), "merge 1280x960")
+    ref = oracle_lib.line_extract(img, 200)
+    _assert_extract_equal(le(img), ref, "line extract 1280x960")
+    L = np.stack([ref[0][n] for n in ("startPointX", "startPointY", "endPointX", "endPointY")], 1).astype(np.float32)
+    np.testing.assert_array_equal(le.pair(L, 20.0, np.float32(np.pi / 4), 1280, 960).view(np.uint32),
+                                  oracle_lib.lil_pair(L, 20.0, np.float32(np.pi / 4), 1280, 960).view(np.uint32))
+    assert len(ref[0]) > 20
+
+
 def test_lsd_large_regions_exercise_queue_overflow():
     """Wide smooth ramps give regions of several thousand pixels (> the 1024-entry LDS ring of the queue),
     thick bars give regions that fail the density test and go through refine / reduce_region_radius."""

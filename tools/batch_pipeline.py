@@ -41,6 +41,7 @@ class BatchPipeline:
         self.stream = stream
         self.ctx = P.Context(local_rank, stream.cuda_stream)
         self.ctx_l = self.ctx if second_stream is None else P.Context(local_rank, second_stream.cuda_stream)
+        self.stream_l = second_stream   # the line pipeline's stream when it runs beside the ORB pipeline (None: one stream)
         self.orb = P.ORBextractor(nfeatures, SCALE, NLEVELS, INI_TH, MIN_TH, ctx=self.ctx, max_batch=B)
         self.cap = self.orb.max_keypoints(w, h)
         self.grid = P.FrameGrid(self.cap, B, ctx=self.ctx)
