@@ -313,6 +313,7 @@ def main():
             host_io["d_depth16"] = torch.empty((B, H, W), dtype=torch.int16, device=dev)
 
     gather = None
+    gather_kind = None
     layout = None
     rec_host = None
 
@@ -348,7 +349,12 @@ def main():
             dist.broadcast(t, 0)
             return t.cpu().numpy()
         with stdout_to_stderr():
-            gather = mg.RecordGather(ctx, layout, B, rank, world, dev, bcast)
+            try:
+                gather = mg.RecordGather(ctx, layout, B, rank, world, dev, bcast)
+            except Exception as e:   # RCCL not loadable through the C ABI on this node: the same records through torch.distributed
+                print(f"[bench] pslfe_gather unavailable ({e}); gathering the records with torch.distributed", file=sys.stderr)
+                gather = mg.TorchRecordGather(ctx, layout, B, world, dev)
+            gather_kind = type(gather).__name__
             step()   # the first exchange initialises the communicator's channels
             gather.wait()
         if args.host_io:
@@ -453,7 +459,8 @@ def main():
                        "mean_matches": round(mean_matches, 1), "host_io": bool(args.host_io), "streams": args.streams,
                        "multi_gpu": ("independent stream per rank; per-frame result records (counts, keypoints, descriptors, point matches, keylines, LBD "
                                      "descriptors, line equations, line matches, fans, planes) packed and all-gathered with RCCL through the C ABI "
-                                     f"(pslfe_gather_all), {layout.bytes} B per frame") if world > 1 else "single GPU"},
+                                     f"({'pslfe_gather_all' if gather_kind == 'RecordGather' else 'torch.distributed all_gather_into_tensor'}), "
+                                     f"{layout.bytes} B per frame") if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": dom_bytes, "ms_per_launch": round(stages[dom]["ms_per_launch"], 4)},

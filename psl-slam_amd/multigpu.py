@@ -143,6 +143,44 @@ class RecordGather:
             self._h = C.c_void_p()
 
 
+class TorchRecordGather:
+    """Same interface as RecordGather, the exchange through torch.distributed (backend nccl = RCCL as well): the fallback when the
+    C ABI cannot load librccl on a node.  The pack kernel is the C ABI's either way."""
+
+    def __init__(self, ctx, layout, nframes, world, device):
+        import torch
+        import psl_slam_amd as P
+        self.P, self.ctx, self.layout, self.nframes, self.world = P, ctx, layout, nframes, world
+        self.send = [torch.empty((nframes, layout.bytes), dtype=torch.uint8, device=device) for _ in range(2)]
+        self.recv = [torch.empty((world, nframes, layout.bytes), dtype=torch.uint8, device=device) for _ in range(2)]
+        self.work = [None, None]
+        self.k = 0
+
+    def submit(self, sources):
+        import torch.distributed as dist
+        P, k = self.P, self.k
+        if self.work[k] is not None:
+            self.work[k].wait()
+        P._check(P.lib().pslfe_record_pack_device(self.ctx._h, C.byref(self.layout.caps), C.byref(sources), C.c_int(self.nframes),
+                                                  C.c_void_p(self.send[k].data_ptr())), "pslfe_record_pack_device")
+        self.work[k] = dist.all_gather_into_tensor(self.recv[k].view(-1), self.send[k].view(-1), async_op=True) if self.world > 1 else None
+        self.k ^= 1
+        return k
+
+    def wait(self):
+        for i in (0, 1):
+            if self.work[i] is not None:
+                self.work[i].wait()
+                self.work[i] = None
+
+    def result(self, k):
+        self.wait()
+        return self.recv[k]
+
+    def close(self):
+        self.wait()
+
+
 class ResultGather:
     """torch.distributed path (gloo in the CPU tests): double-buffered all-gather of one step's tensors, e.g. the [F][bytes] record
     tensor; overlap with the next step's compute."""

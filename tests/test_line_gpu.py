@@ -395,3 +395,26 @@ def test_full_size_line_batch_properties():
         L = np.stack([k[m] for m in ("startPointX", "startPointY", "endPointX", "endPointY")], 1).astype(np.float32)
         np.testing.assert_array_equal(le.fans_fetch(f).view(np.uint32), oracle_lib.lil_pair(L, 20.0, np.float32(np.pi / 4), 640, 480).view(np.uint32))
     le.ctx.device_free(d_ptr)
+
+
+def test_line_extractor_many_random_scenes_in_one_batch():
+    """40 frames of 40 different scenes (textured and structure-like, random time steps) in one launch, every one compared with the
+    oracle bit for bit: keylines, LBD rows, line equations and fans."""
+    import oracle_lib
+    import psl_slam_amd as P
+    rng = np.random.default_rng(2024)
+    frames = np.stack([_scene("desk" if i % 3 == 0 else "struct", 100 + i, int(rng.integers(0, 30))) for i in range(40)], 0)
+    le = P.LINEextractor(1, 1.2, 200, 0.0, max_batch=len(frames))
+    d_ptr, _ = le.ctx.device_array(frames)
+    le.extract_batch_device(d_ptr, len(frames), 640, 480, 640, 640 * 480)
+    le.pair_batch_device(20.0, np.float32(np.pi / 4))
+    nkl = 0
+    for f in range(len(frames)):
+        k, dsc, eq, st = le.fetch(f)
+        assert st == 0
+        _assert_extract_equal((k, dsc, eq), oracle_lib.line_extract(frames[f], 200), f"scene {f}")
+        L = np.stack([k[m] for m in ("startPointX", "startPointY", "endPointX", "endPointY")], 1).astype(np.float32) if len(k) else np.zeros((0, 4), np.float32)
+        np.testing.assert_array_equal(le.fans_fetch(f).view(np.uint32), oracle_lib.lil_pair(L, 20.0, np.float32(np.pi / 4), 640, 480).view(np.uint32))
+        nkl += len(k)
+    assert nkl > 400
+    le.ctx.device_free(d_ptr)
