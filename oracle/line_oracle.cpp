@@ -149,7 +149,10 @@ struct Lsd {
         return n_theta <= prec;
     }
 
+    std::vector<int32_t>* debug_grow = nullptr;  // tap: per region_grow call [-1, n] then n x (x, y, index of the entry that added it)
     void region_grow(int sx, int sy, std::vector<RegionPoint>& reg, int& reg_size, double& reg_angle, double prec) {
+        const size_t log0 = debug_grow ? debug_grow->size() : 0;
+        if (debug_grow) { debug_grow->push_back(-1); debug_grow->push_back(0); debug_grow->push_back(sx); debug_grow->push_back(sy); debug_grow->push_back(-1); }
         reg_size = 1;
         int addr = sx + sy * W;
         reg[0] = {sx, sy, angles[addr], modgrad[addr]};
@@ -167,12 +170,14 @@ struct Lsd {
                         used[c] = 1;
                         const double angle = angles[c];
                         reg[reg_size++] = {xx, yy, angle, modgrad[c]};
+                        if (debug_grow) { debug_grow->push_back(xx); debug_grow->push_back(yy); debug_grow->push_back(i); }
                         sumdx += pso_cosf(float(angle));
                         sumdy += pso_sinf(float(angle));
                         reg_angle = pso_fast_atan2(sumdy, sumdx) * DEG_TO_RADS;
                     }
             }
         }
+        if (debug_grow) (*debug_grow)[log0 + 1] = reg_size;
     }
 
     static double angle_diff_signed(double a, double b) {
@@ -868,6 +873,18 @@ int pso_lsd_rects(const uint8_t* gray, int w, int h, int stride, double* rects, 
     const int n = (int)r.size() / 12;
     for (int i = 0; i < n && i < cap; ++i) memcpy(rects + 12 * i, &r[12 * (size_t)i], 96);
     return n;
+}
+
+// growth log of every region_grow call (analysis of the queue order, tools/grow_stats.py); returns the int32 count
+int pso_lsd_growlog(const uint8_t* gray, int w, int h, int stride, int32_t* out, int cap) {
+    Lsd lsd;
+    std::vector<int32_t> g;
+    std::vector<float> v;
+    lsd.debug_grow = &g;
+    lsd.detect(gray, w, h, stride, v);
+    const int n = (int)std::min<size_t>(g.size(), (size_t)cap);
+    memcpy(out, g.data(), sizeof(int32_t) * (size_t)n);
+    return (int)g.size();
 }
 
 // LSD + contrib wrapper clamp: returns number of segments, lines = x1,y1,x2,y2 floats

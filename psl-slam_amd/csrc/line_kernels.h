@@ -345,6 +345,7 @@ struct LsdW {
     const float2* seedt;   // (float)cos, (float)sin of the double angle (seed pixels)
     const double* sctab;
     uint32_t* ring;   // LDS mirror of reg[idx & (RING-1)]
+    uint32_t* map;    // LDS [64]: window lane -> queue index + 1 (lsdg_region_grow4)
     double* term;     // LDS [3][64]
     uint32_t* reg;    // HBM queue
 };
@@ -500,6 +501,153 @@ __device__ int lsdg_region_grow(const LsdW& F, int sx, int sy, double* reg_angle
     return reg_size;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Region growing in WINDOW ROUNDS.  The queue order of the reference (breadth first, 3 x 3 neighbours in raster order, the
+// region angle brought up to date after every pixel) is kept exactly; what changes is how much of it one memory round trip serves.
+// A round loads the 16-byte records of an 8 x 8 pixel window (lane = pixel, row major; the first entry to pop sits at column 3,
+// row 1: a region's seed is its first pixel in raster order, growth goes down and sideways) and then pops queue entries for as long
+// as the popped pixel lies in the window's 6 x 6 interior, i.e. all of its neighbours are lanes of the wave - including entries
+// pushed in this very round.  On a line 2 - 3 pixels wide a round advances the frontier by 5 - 6 pixels instead of one (rounds per
+// 640x480 frame: 12.5 k with the 7-entries-per-round scheme before, 4.6 k now; tools/grow_stats.py replays the oracle's queue).
+//  * which lane holds queue entry i: `seq` (lane -> queue index): entries that were in the queue when the round began are mapped
+//    through a 64-word LDS table (up to 64 of them), entries pushed in the round get theirs when they are accepted;
+//  * neighbours of the popped lane le: the bit pattern 0x070707 << (le - 9) of a wave-uniform 64-bit mask, ANDed with `live`
+//    (defined angle, not used); ascending bit order is the reference's visiting order; all of this is scalar-unit work;
+//  * decision: the reference compares fold(|fastAtan2(sum) - a|) with prec.  The angle phi between the running sum S and the
+//    pixel's unit vector u = (cosf a, sinf a) - both are at hand - differs from that quantity by < 4e-4 rad (fastAtan2's error
+//    < 0.02 deg, tests/test_oracle_line_cpu.py; float rounding ~1e-6), so with a margin m = 2e-3 rad
+//        |S x u| <= tan(prec - m) (S . u)  =>  joins,      |S x u| >= tan(prec + m) (S . u)  =>  does not
+//    (8 vector instructions for all 64 lanes, against ~45 for fastAtan2 + the f64 compare); only a lane in between - 0.5 % of the
+//    decisions - takes the exact path, which is the reference's arithmetic.  Valid while prec + m < 1.5 rad (then every added
+//    vector has a positive projection on S and |S| >= 1); a refinement tolerance beyond that uses the exact path only;
+//  * the sums are added in acceptance order (bit-identical), the region angle is evaluated only when the exact path or the end of
+//    the region needs it;
+//  * marks: one store instruction per round (the accepted lanes mark their own records) and one LDS store for the queue.  The next
+//    round's load is issued right behind that store: the pixels of the previous round are therefore recognised from its
+//    acceptance mask (PA, window origin pox / poy), everything older has completed before the previous round's load returned
+//    (vector-memory operations complete in issue order), so the `used` word needs no wait of its own.
+// ---------------------------------------------------------------------------------------------
+#define PSL_G4_MARGIN 2.0e-3f
+struct LsdgFast { float t_hi, t_lo; int ok; };
+__device__ __forceinline__ LsdgFast lsdg_fast_setup(double prec) {
+    LsdgFast f;
+    const float p = (float)prec;
+    f.ok = p + PSL_G4_MARGIN < 1.5f;
+    f.t_hi = p - PSL_G4_MARGIN > 0.f ? psl_tanf(p - PSL_G4_MARGIN) * (1.f - 1e-5f) : -1.f;
+    f.t_lo = f.ok ? psl_tanf(p + PSL_G4_MARGIN) * (1.f + 1e-5f) : 0.f;
+    return f;
+}
+
+__device__ int lsdg_region_grow4(const LsdW& F, int sx, int sy, double* reg_angle_out, double prec, const LsdgFast fc) {
+    typedef __attribute__((address_space(3))) uint32_t lds_u32;
+    lds_u32* ring = (lds_u32*)F.ring;
+    lds_u32* map = (lds_u32*)F.map;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // marks and releases of everything before this region have completed
+    const int lane = F.lane, lx = lane & 7, ly = lane >> 3;
+    const int addr0 = sx + sy * F.W;
+    int reg_size = 1;
+    if (lane == 0) {
+        lsdg_mark(F, addr0, 1);
+        ring[0] = (uint32_t)sx | ((uint32_t)sy << 16);
+    }
+    float reg_deg = F.ang[addr0];
+    const float2 t0 = F.seedt[addr0];
+    float sumdx = t0.x, sumdy = t0.y;
+    bool angle_dirty = false;
+    unsigned long long PA = 1ull;  // the seed: "accepted in the previous round", window origin = the seed itself
+    int pox = sx, poy = sy;
+    int i = 0;
+    while (i < reg_size) {
+        const int rs0 = reg_size;
+        const int qi = i + lane;
+        uint32_t q = 0xffffffffu;
+        if (reg_size - i > PSL_LSD_RING) {  // uniform, rare: the frontier lags > 1024 entries; these have been flushed to HBM
+            if (qi < reg_size - PSL_LSD_RING / 2) {
+                const uint32_t g = F.reg[qi];
+                asm volatile("v_mov_b32 %0, %1" : "=v"(q) : "v"(g));
+            }
+        } else if (qi < reg_size) {
+            q = ring[qi & (PSL_LSD_RING - 1)];
+        }
+        const uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane((int)q);
+        const int ox = (int)(e & 0xffff) - 3, oy = (int)(e >> 16) - 1;
+        const int x = ox + lx, y = oy + ly;
+        const bool inside = (unsigned)x < (unsigned)F.W && (unsigned)y < (unsigned)F.H;
+        const int cidx = inside ? x + y * F.W : addr0;
+        const float4 t = F.trig[cidx];
+        // queue entry -> lane of the window (while the load is in flight)
+        const int qx = (int)(q & 0xffff) - ox, qy = (int)(q >> 16) - oy;
+        map[lane] = 0u;
+        __builtin_amdgcn_wave_barrier();
+        if ((unsigned)qx < 8u && (unsigned)qy < 8u) map[qy * 8 + qx] = (uint32_t)(qi + 1);
+        __builtin_amdgcn_wave_barrier();
+        int seq = (int)map[lane] - 1;
+        const int px = x - pox, py = y - poy;
+        const bool pa = (unsigned)px < 8u && (unsigned)py < 8u && ((PA >> (py * 8 + px)) & 1ull) != 0ull;
+        const uint32_t xy = (uint32_t)x | ((uint32_t)y << 16);
+        const float cs = t.x, sn = t.y, a = t.z;
+        unsigned long long live = __ballot(inside && a != PSL_LSD_NOTDEF && __float_as_uint(t.w) == 0u && !pa);
+        unsigned long long acc_round = 0ull, RA = 0ull, RN = 0ull;
+        bool dirty = true;
+        for (;;) {
+            const unsigned long long m = __ballot(seq == i) & 0x007E7E7E7E7E7E00ull;  // in the window, and in its interior
+            if (!m) break;
+            const int le = __ffsll((long long)m) - 1;
+            unsigned long long cand = (0x070707ull << (le - 9)) & live;
+            ++i;
+            while (cand) {
+                if (dirty) {
+                    if (fc.ok) {
+                        const float dot = __fmaf_rn(sumdx, cs, sumdy * sn);
+                        const float cr = __builtin_fabsf(__fmaf_rn(sumdx, sn, -(sumdy * cs)));
+                        RA = __ballot(cr <= fc.t_hi * dot);
+                        RN = __ballot(cr >= fc.t_lo * dot);
+                    }
+                    dirty = false;
+                }
+                const int c = __ffsll((long long)cand) - 1;
+                const unsigned long long bit = 1ull << c;
+                cand &= cand - 1ull;
+                bool accept;
+                if (RA & bit) accept = true;
+                else if (RN & bit) accept = false;
+                else {
+                    if (angle_dirty) { reg_deg = psl_fast_atan2(sumdy, sumdx); angle_dirty = false; }
+                    const double ad = PSL_DMUL((double)a, PSL_DEG2RAD), th = PSL_DMUL((double)reg_deg, PSL_DEG2RAD);
+                    accept = (__ballot(lsdg_aligned(ad, th, prec)) & bit) != 0ull;
+                }
+                if (accept) {
+                    live &= ~bit; acc_round |= bit;
+                    const float csL = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cs), c));
+                    const float snL = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sn), c));
+                    sumdx = PSL_FADD(sumdx, csL);
+                    sumdy = PSL_FADD(sumdy, snL);
+                    if (lane == c) seq = reg_size;
+                    ++reg_size;
+                    dirty = true; angle_dirty = true;
+                }
+            }
+            if (i >= reg_size) break;
+        }
+        // the round's pixels: queue entries and marks, one store instruction each
+        if ((acc_round >> lane) & 1ull) {
+            ring[seq & (PSL_LSD_RING - 1)] = xy;
+            lsdg_mark(F, cidx, 1);
+        }
+        if ((reg_size >> 9) != (rs0 >> 9)) {  // a block of 512 entries is complete: to HBM, long before the ring wraps over it
+            __builtin_amdgcn_wave_barrier();
+            const int b0 = ((reg_size >> 9) - 1) << 9;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) F.reg[b0 + k * 64 + lane] = ring[(b0 + k * 64 + lane) & (PSL_LSD_RING - 1)];
+        }
+        PA = acc_round; pox = ox; poy = oy;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (angle_dirty) reg_deg = psl_fast_atan2(sumdy, sumdx);
+    *reg_angle_out = PSL_DMUL((double)reg_deg, PSL_DEG2RAD);
+    return reg_size;
+}
+
 __device__ __forceinline__ double lsdw_wave_max(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { const double u = __shfl_xor(v, o); v = u > v ? u : v; }
@@ -631,7 +779,7 @@ __device__ int lsdw_refine(const LsdW& F, int reg_size, double reg_angle, double
     const double sum = lsdw_lane_f64(acc, 0), s_sum = lsdw_lane_f64(acc, 1);
     const double mean_angle = sum / (double)n;
     const double tau = PSL_DMUL(2.0, __dsqrt_rn(PSL_DADD(PSL_DSUB(s_sum, PSL_DMUL(PSL_DMUL(2.0, mean_angle), sum)) / (double)n, PSL_DMUL(mean_angle, mean_angle))));
-    reg_size = lsdg_region_grow(F, x0, y0, &reg_angle, tau);
+    reg_size = lsdg_region_grow4(F, x0, y0, &reg_angle, tau, lsdg_fast_setup(tau));
     if (reg_size < 2) return 0;
     lsdw_region2rect(F, reg_size, reg_angle, prec, rec);
     density = psl_lsd_density(reg_size, *rec);
@@ -697,13 +845,15 @@ __global__ __launch_bounds__(64, PSL_GROW_WAVES) void k_lsd_grow3(LineParams P, 
                                                    float* __restrict__ seg, int* __restrict__ nseg, double* __restrict__ rects) {
     __shared__ uint32_t s_ring[PSL_LSD_RING];
     __shared__ double s_term[3 * 64];
+    __shared__ uint32_t s_map[64];
     const int frame = blockIdx.x, lane = threadIdx.x;
     const size_t npx = (size_t)P.W * P.H;
     const int words = (int)((npx + 31) >> 5);
     LsdW F;
     F.W = P.W; F.H = P.H; F.lane = lane;
     F.ang = angdeg + frame * npx; F.mod = modgrad + frame * npx; F.trig = trig + frame * npx; F.reg = reg + frame * npx;
-    F.seedt = seedt + frame * npx; F.ring = s_ring; F.term = s_term; F.sctab = P.sctab;
+    F.seedt = seedt + frame * npx; F.ring = s_ring; F.term = s_term; F.sctab = P.sctab; F.map = s_map;
+    const LsdgFast fcP = lsdg_fast_setup(P.prec);
     // (the used flags start at 0: k_lsd_grad has just written the records)
     (void)words;
     float* out = seg + (size_t)frame * P.maxseg * 4;
@@ -758,7 +908,7 @@ __global__ __launch_bounds__(64, PSL_GROW_WAVES) void k_lsd_grow3(LineParams P, 
                 const int adx = base + q * 64 + s;
                 const int y = adx / P.W, x = adx - y * P.W;
                 double reg_angle;
-                int reg_size = lsdg_region_grow(F, x, y, &reg_angle, P.prec);
+                int reg_size = lsdg_region_grow4(F, x, y, &reg_angle, P.prec, fcP);
                 stale = true;
                 dirty = true;
                 if (reg_size < P.min_reg_size) continue;
