@@ -149,6 +149,7 @@ struct Lsd {
         return n_theta <= prec;
     }
 
+    long debug_cands = 0;  // with debug_grow: neighbours with a defined angle, not used, that were tested
     std::vector<int32_t>* debug_grow = nullptr;  // tap: per region_grow call [-1, n] then n x (x, y, index of the entry that added it)
     void region_grow(int sx, int sy, std::vector<RegionPoint>& reg, int& reg_size, double& reg_angle, double prec) {
         const size_t log0 = debug_grow ? debug_grow->size() : 0;
@@ -165,7 +166,8 @@ struct Lsd {
             int yy_min = std::max(rp.y - 1, 0), yy_max = std::min(rp.y + 1, H - 1);
             for (int yy = yy_min; yy <= yy_max; ++yy) {
                 int c = xx_min + yy * W;
-                for (int xx = xx_min; xx <= xx_max; ++xx, ++c)
+                for (int xx = xx_min; xx <= xx_max; ++xx, ++c) {
+                    if (debug_grow && used[c] != 1 && angles[c] != NOTDEF) ++debug_cands;
                     if (used[c] != 1 && is_aligned(c, reg_angle, prec)) {
                         used[c] = 1;
                         const double angle = angles[c];
@@ -175,6 +177,7 @@ struct Lsd {
                         sumdy += pso_sinf(float(angle));
                         reg_angle = pso_fast_atan2(sumdy, sumdx) * DEG_TO_RADS;
                     }
+                }
             }
         }
         if (debug_grow) (*debug_grow)[log0 + 1] = reg_size;
@@ -882,6 +885,7 @@ int pso_lsd_growlog(const uint8_t* gray, int w, int h, int stride, int32_t* out,
     std::vector<float> v;
     lsd.debug_grow = &g;
     lsd.detect(gray, w, h, stride, v);
+    g.push_back(-2); g.push_back((int32_t)lsd.debug_cands);
     const int n = (int)std::min<size_t>(g.size(), (size_t)cap);
     memcpy(out, g.data(), sizeof(int32_t) * (size_t)n);
     return (int)g.size();

@@ -346,6 +346,7 @@ struct LsdW {
     const double* sctab;
     uint32_t* ring;   // LDS mirror of reg[idx & (RING-1)]
     uint32_t* map;    // LDS [64]: window lane -> queue index + 1 (lsdg_region_grow4)
+    unsigned long long interior;  // lanes of the 8 x 8 window's 6 x 6 interior
     double* term;     // LDS [3][64]
     uint32_t* reg;    // HBM queue
 };
@@ -528,37 +529,118 @@ __device__ int lsdg_region_grow(const LsdW& F, int sx, int sy, double* reg_angle
 //    (vector-memory operations complete in issue order), so the `used` word needs no wait of its own.
 // ---------------------------------------------------------------------------------------------
 #define PSL_G4_MARGIN 2.0e-3f
+#ifdef PSL_GROW_STATS   // diagnostic build only (PSLFE_EXTRA_FLAGS=-DPSL_GROW_STATS): loop trip counts of frame 0, printed by the kernel
+__device__ unsigned long long g_gstats[16];
+#define GS(k) (++gs[k])
+#else
+#define GS(k)
+#endif
 struct LsdgFast { float t_hi, t_lo; int ok; };
 __device__ __forceinline__ LsdgFast lsdg_fast_setup(double prec) {
     LsdgFast f;
     const float p = (float)prec;
     f.ok = p + PSL_G4_MARGIN < 1.5f;
-    f.t_hi = p - PSL_G4_MARGIN > 0.f ? psl_tanf(p - PSL_G4_MARGIN) * (1.f - 1e-5f) : -1.f;
-    f.t_lo = f.ok ? psl_tanf(p + PSL_G4_MARGIN) * (1.f + 1e-5f) : 0.f;
+    // cr < t_hi max(dot, 0) => joins, cr >= t_lo max(dot, 0) => does not; -1 / +inf: never true (inf * 0 = NaN compares false)
+    f.t_hi = f.ok && p - PSL_G4_MARGIN > 0.f ? psl_tanf(p - PSL_G4_MARGIN) * (1.f - 1e-5f) : -1.f;
+    f.t_lo = f.ok ? psl_tanf(p + PSL_G4_MARGIN) * (1.f + 1e-5f) : __builtin_inff();
     return f;
 }
+// The marks of the last round that ran (of this region or of the one before): possibly still on their way to memory.
+struct LsdgPend { unsigned long long PA; int pox, poy; };
 
-__device__ int lsdg_region_grow4(const LsdW& F, int sx, int sy, double* reg_angle_out, double prec, const LsdgFast fc) {
+// The decision loop over the candidates of one popped entry, hand-scheduled: hipcc spends ~31 scalar instructions per accepted pixel on
+// this wave-uniform mask logic (every uniform bool becomes a 64-bit mask, a compare and a branch); written out it is 15.  `cand`:
+// candidates still to decide (absolute lane positions, ascending = visiting order).  Per iteration: masks of sure joins / sure
+// rejects against the current sums unless still valid (`fresh`), skip the sure rejects in front, take the first other candidate c:
+// a sure join is added (sums in order, its queue index, `live`), anything else ends the block with c returned (it is removed from
+// cand; the caller runs the reference's arithmetic for it).  Returns -1 when all candidates are decided.
+// gfx950 wait states observed: a VALU-written SGPR / VCC is read by a VALU instruction no sooner than the third instruction after it.
+__device__ __forceinline__ int lsdg_decide(unsigned long long& cand, unsigned long long& live, unsigned long long& RA, unsigned long long& RN, int& fresh,
+                                           int& reg_size, float& sumdx, float& sumdy, int& seq, float cs, float sn, int lane, float t_hi, float t_lo) {
+    int cx, c, sa, sb;
+    float t0, t1, t2;
+    unsigned long long tm;
+    asm volatile(
+        "s_mov_b32 %[cx], -1\n\t"
+        ".Ltop%=:\n\t"
+        "s_cmp_lg_u32 %[fresh], 0\n\t"
+        "s_cbranch_scc1 .Lhave%=\n\t"
+        "v_mul_f32 %[t0], %[sy], %[sn]\n\t"
+        "v_mul_f32 %[t1], %[sy], %[cs]\n\t"
+        "v_fmac_f32 %[t0], %[sx], %[cs]\n\t"
+        "v_fma_f32 %[t1], %[sx], %[sn], -%[t1]\n\t"
+        "v_max_f32 %[t0], 0, %[t0]\n\t"
+        "v_mul_f32 %[t2], %[thi], %[t0]\n\t"
+        "v_mul_f32 %[t0], %[tlo], %[t0]\n\t"
+        "v_cmp_lt_f32 %[RA], |%[t1]|, %[t2]\n\t"
+        "v_cmp_ge_f32 %[RN], |%[t1]|, %[t0]\n\t"
+        "s_mov_b32 %[fresh], 1\n\t"
+        ".Lhave%=:\n\t"
+        "s_andn2_b64 %[tm], %[cand], %[RN]\n\t"
+        "s_cbranch_scc0 .Lnone%=\n\t"
+        "s_ff1_i32_b64 %[c], %[tm]\n\t"
+        "s_lshl_b64 %[tm], -2, %[c]\n\t"
+        "s_and_b64 %[cand], %[cand], %[tm]\n\t"
+        "s_bitcmp1_b64 %[RA], %[c]\n\t"
+        "s_cbranch_scc0 .Lamb%=\n\t"
+        "v_readlane_b32 %[sa], %[cs], %[c]\n\t"
+        "v_readlane_b32 %[sb], %[sn], %[c]\n\t"
+        "v_cmp_eq_u32 vcc, %[c], %[lane]\n\t"
+        "v_mov_b32 %[t0], %[rs]\n\t"
+        "v_add_f32 %[sx], %[sa], %[sx]\n\t"
+        "v_add_f32 %[sy], %[sb], %[sy]\n\t"
+        "v_cndmask_b32 %[seq], %[seq], %[t0], vcc\n\t"
+        "s_bitset0_b64 %[live], %[c]\n\t"
+        "s_add_i32 %[rs], %[rs], 1\n\t"
+        "s_mov_b32 %[fresh], 0\n\t"
+        "s_cmp_lg_u64 %[cand], 0\n\t"
+        "s_cbranch_scc1 .Ltop%=\n\t"
+        "s_branch .Ldone%=\n\t"
+        ".Lamb%=:\n\t"
+        "s_mov_b32 %[cx], %[c]\n\t"
+        "s_branch .Ldone%=\n\t"
+        ".Lnone%=:\n\t"
+        "s_mov_b64 %[cand], 0\n\t"
+        ".Ldone%=:\n\t"
+        : [cand] "+s"(cand), [live] "+s"(live), [RA] "+s"(RA), [RN] "+s"(RN), [fresh] "+s"(fresh), [rs] "+s"(reg_size), [sx] "+v"(sumdx), [sy] "+v"(sumdy),
+          [seq] "+v"(seq), [cx] "=&s"(cx), [c] "=&s"(c), [sa] "=&s"(sa), [sb] "=&s"(sb), [tm] "=&s"(tm), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2)
+        : [cs] "v"(cs), [sn] "v"(sn), [lane] "v"(lane), [thi] "v"(t_hi), [tlo] "v"(t_lo)
+        : "vcc", "scc");
+    return cx;
+}
+
+// `regrow`: the refinement's second growth - its releases of the region's pixels must have completed, nothing is pending.
+// `touched`: set when the region took a pixel whose raster index lies in (seed, trip_end): only then has the seed scan to look
+// at the `used` words of its current 256-pixel trip again.
+__device__ int lsdg_region_grow4(const LsdW& F, int sx, int sy, double* reg_angle_out, double prec, const LsdgFast fc, LsdgPend& pd,
+                                 bool regrow, int trip_end, bool& touched) {
     typedef __attribute__((address_space(3))) uint32_t lds_u32;
     lds_u32* ring = (lds_u32*)F.ring;
     lds_u32* map = (lds_u32*)F.map;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // marks and releases of everything before this region have completed
+    if (regrow) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        pd.PA = 0ull;
+    }
     const int lane = F.lane, lx = lane & 7, ly = lane >> 3;
     const int addr0 = sx + sy * F.W;
     int reg_size = 1;
-    if (lane == 0) {
-        lsdg_mark(F, addr0, 1);
-        ring[0] = (uint32_t)sx | ((uint32_t)sy << 16);
-    }
-    float reg_deg = F.ang[addr0];
+    const uint32_t xy0 = (uint32_t)sx | ((uint32_t)sy << 16);
+    if (lane == 0) ring[0] = xy0;  // the seed's mark leaves with the marks of the first round (it is lane 11 of that window)
+    float reg_deg = F.ang[addr0];       // these two loads and the first window's are in flight together
     const float2 t0 = F.seedt[addr0];
-    float sumdx = t0.x, sumdy = t0.y;
-    bool angle_dirty = false;
-    unsigned long long PA = 1ull;  // the seed: "accepted in the previous round", window origin = the seed itself
-    int pox = sx, poy = sy;
+    float sumdx = 0.f, sumdy = 0.f;
+#ifdef PSL_GROW_STATS
+    unsigned gs[16] = {0};
+#endif
+    GS(0);
+    bool first = true;
+    int rs_angle = 1;  // the region size reg_deg belongs to (the seed's own angle at 1)
+    unsigned long long PA = pd.PA;
+    int pox = pd.pox, poy = pd.poy;
     int i = 0;
     while (i < reg_size) {
         const int rs0 = reg_size;
+        GS(1);
         const int qi = i + lane;
         uint32_t q = 0xffffffffu;
         if (reg_size - i > PSL_LSD_RING) {  // uniform, rare: the frontier lags > 1024 entries; these have been flushed to HBM
@@ -569,7 +651,7 @@ __device__ int lsdg_region_grow4(const LsdW& F, int sx, int sy, double* reg_angl
         } else if (qi < reg_size) {
             q = ring[qi & (PSL_LSD_RING - 1)];
         }
-        const uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane((int)q);
+        const uint32_t e = first ? xy0 : (uint32_t)__builtin_amdgcn_readfirstlane((int)q);
         const int ox = (int)(e & 0xffff) - 3, oy = (int)(e >> 16) - 1;
         const int x = ox + lx, y = oy + ly;
         const bool inside = (unsigned)x < (unsigned)F.W && (unsigned)y < (unsigned)F.H;
@@ -585,55 +667,44 @@ __device__ int lsdg_region_grow4(const LsdW& F, int sx, int sy, double* reg_angl
         const int px = x - pox, py = y - poy;
         const bool pa = (unsigned)px < 8u && (unsigned)py < 8u && ((PA >> (py * 8 + px)) & 1ull) != 0ull;
         const uint32_t xy = (uint32_t)x | ((uint32_t)y << 16);
+        if (first) { sumdx = t0.x; sumdy = t0.y; }
         const float cs = t.x, sn = t.y, a = t.z;
-        unsigned long long live = __ballot(inside && a != PSL_LSD_NOTDEF && __float_as_uint(t.w) == 0u && !pa);
-        unsigned long long acc_round = 0ull, RA = 0ull, RN = 0ull;
-        bool dirty = true;
+        // a lane that holds a queue entry is a pixel of the region (the seed among them: its mark is not in memory yet)
+        unsigned long long live = __ballot(inside && a != PSL_LSD_NOTDEF && __float_as_uint(t.w) == 0u && !pa && seq < 0);
+        unsigned long long RA = 0ull, RN = 0ull;  // valid while the sums are the ones they were computed from (`fresh`)
+        int fresh = 0;
         for (;;) {
-            const unsigned long long m = __ballot(seq == i) & 0x007E7E7E7E7E7E00ull;  // in the window, and in its interior
-            if (!m) break;
-            const int le = __ffsll((long long)m) - 1;
-            unsigned long long cand = (0x070707ull << (le - 9)) & live;
+            const unsigned long long m = __ballot(seq == i) & F.interior;  // in the window, and in its 6 x 6 interior
+            if (!m) break;  // (also when i == reg_size: no lane holds an index that does not exist yet)
+            const int sh = __ffsll((long long)m) - 10;
+            unsigned long long cand = (0x070707ull << sh) & live;  // the 3 x 3 neighbours, ascending bit = visiting order
             ++i;
+            GS(2);
+            if (cand) GS(3);
             while (cand) {
-                if (dirty) {
-                    if (fc.ok) {
-                        const float dot = __fmaf_rn(sumdx, cs, sumdy * sn);
-                        const float cr = __builtin_fabsf(__fmaf_rn(sumdx, sn, -(sumdy * cs)));
-                        RA = __ballot(cr <= fc.t_hi * dot);
-                        RN = __ballot(cr >= fc.t_lo * dot);
-                    }
-                    dirty = false;
-                }
-                const int c = __ffsll((long long)cand) - 1;
-                const unsigned long long bit = 1ull << c;
-                cand &= cand - 1ull;
-                bool accept;
-                if (RA & bit) accept = true;
-                else if (RN & bit) accept = false;
-                else {
-                    if (angle_dirty) { reg_deg = psl_fast_atan2(sumdy, sumdx); angle_dirty = false; }
-                    const double ad = PSL_DMUL((double)a, PSL_DEG2RAD), th = PSL_DMUL((double)reg_deg, PSL_DEG2RAD);
-                    accept = (__ballot(lsdg_aligned(ad, th, prec)) & bit) != 0ull;
-                }
-                if (accept) {
-                    live &= ~bit; acc_round |= bit;
-                    const float csL = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cs), c));
-                    const float snL = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sn), c));
-                    sumdx = PSL_FADD(sumdx, csL);
-                    sumdy = PSL_FADD(sumdy, snL);
-                    if (lane == c) seq = reg_size;
-                    ++reg_size;
-                    dirty = true; angle_dirty = true;
-                }
+                GS(4);
+                const int c = lsdg_decide(cand, live, RA, RN, fresh, reg_size, sumdx, sumdy, seq, cs, sn, lane, fc.t_hi, fc.t_lo);
+                if (c < 0) break;
+                // lane c is within the margin of the threshold: the reference's arithmetic
+                GS(6);
+                if (rs_angle != reg_size) { reg_deg = psl_fast_atan2(sumdy, sumdx); rs_angle = reg_size; }
+                const double ad = PSL_DMUL((double)a, PSL_DEG2RAD), th = PSL_DMUL((double)reg_deg, PSL_DEG2RAD);
+                if (!((__ballot(lsdg_aligned(ad, th, prec)) >> c) & 1ull)) continue;
+                sumdx = PSL_FADD(sumdx, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cs), c)));
+                sumdy = PSL_FADD(sumdy, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sn), c)));
+                if (lane == c) seq = reg_size;
+                live &= ~(1ull << c);
+                ++reg_size;
+                fresh = 0;
             }
-            if (i >= reg_size) break;
         }
         // the round's pixels: queue entries and marks, one store instruction each
-        if ((acc_round >> lane) & 1ull) {
+        const unsigned long long acc_round = __ballot(seq >= (first ? 0 : rs0));
+        if (seq >= (first ? 0 : rs0)) {
             ring[seq & (PSL_LSD_RING - 1)] = xy;
             lsdg_mark(F, cidx, 1);
         }
+        if (__ballot(seq >= rs0 && cidx > addr0 && cidx < trip_end)) touched = true;
         if ((reg_size >> 9) != (rs0 >> 9)) {  // a block of 512 entries is complete: to HBM, long before the ring wraps over it
             __builtin_amdgcn_wave_barrier();
             const int b0 = ((reg_size >> 9) - 1) << 9;
@@ -641,9 +712,13 @@ __device__ int lsdg_region_grow4(const LsdW& F, int sx, int sy, double* reg_angl
             for (int k = 0; k < 8; ++k) F.reg[b0 + k * 64 + lane] = ring[(b0 + k * 64 + lane) & (PSL_LSD_RING - 1)];
         }
         PA = acc_round; pox = ox; poy = oy;
+        first = false;
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (angle_dirty) reg_deg = psl_fast_atan2(sumdy, sumdx);
+    pd.PA = PA; pd.pox = pox; pd.poy = poy;
+    if (rs_angle != reg_size) reg_deg = psl_fast_atan2(sumdy, sumdx);
+#ifdef PSL_GROW_STATS
+    if (blockIdx.x == 0 && lane == 0) for (int k = 0; k < 16; ++k) g_gstats[k] += gs[k];
+#endif
     *reg_angle_out = PSL_DMUL((double)reg_deg, PSL_DEG2RAD);
     return reg_size;
 }
@@ -747,7 +822,8 @@ __device__ void lsdw_region2rect(const LsdW& F, int reg_size, double reg_angle, 
     rec->theta = theta; rec->dx = dx; rec->dy = dy;  // read by the NFA validation (LSD_REFINE_ADV) only
 }
 
-__device__ int lsdw_refine(const LsdW& F, int reg_size, double reg_angle, double prec, LsdRect* rec, double density_th) {
+__device__ int lsdw_refine(const LsdW& F, int reg_size, double reg_angle, double prec, LsdRect* rec, double density_th, LsdgPend& pd, int trip_end,
+                           bool& touched) {
     double density = psl_lsd_density(reg_size, *rec);
     if (density >= density_th) return reg_size;
     const uint32_t r0 = lsdw_reg(F, 0, reg_size);
@@ -779,7 +855,7 @@ __device__ int lsdw_refine(const LsdW& F, int reg_size, double reg_angle, double
     const double sum = lsdw_lane_f64(acc, 0), s_sum = lsdw_lane_f64(acc, 1);
     const double mean_angle = sum / (double)n;
     const double tau = PSL_DMUL(2.0, __dsqrt_rn(PSL_DADD(PSL_DSUB(s_sum, PSL_DMUL(PSL_DMUL(2.0, mean_angle), sum)) / (double)n, PSL_DMUL(mean_angle, mean_angle))));
-    reg_size = lsdg_region_grow4(F, x0, y0, &reg_angle, tau, lsdg_fast_setup(tau));
+    reg_size = lsdg_region_grow4(F, x0, y0, &reg_angle, tau, lsdg_fast_setup(tau), pd, true, trip_end, touched);
     if (reg_size < 2) return 0;
     lsdw_region2rect(F, reg_size, reg_angle, prec, rec);
     density = psl_lsd_density(reg_size, *rec);
@@ -807,7 +883,11 @@ __device__ int lsdw_refine(const LsdW& F, int reg_size, double reg_angle, double
                 --i;
             }
         }
-        if (reg_size < 2) return 0;
+        if (reg_size < 2) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the releases above have to land before the next region looks
+            pd.PA = 0ull;
+            return 0;
+        }
         for (int j = F.lane; j < min(reg_size, PSL_LSD_RING); j += 64) {  // ring must mirror the last RING entries
             const int idx = reg_size - 1 - j;
             F.ring[idx & (PSL_LSD_RING - 1)] = F.reg[idx];
@@ -816,6 +896,8 @@ __device__ int lsdw_refine(const LsdW& F, int reg_size, double reg_angle, double
         lsdw_region2rect(F, reg_size, reg_angle, prec, rec);
         density = psl_lsd_density(reg_size, *rec);
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    pd.PA = 0ull;
     return reg_size;
 }
 
@@ -853,7 +935,10 @@ __global__ __launch_bounds__(64, PSL_GROW_WAVES) void k_lsd_grow3(LineParams P, 
     F.W = P.W; F.H = P.H; F.lane = lane;
     F.ang = angdeg + frame * npx; F.mod = modgrad + frame * npx; F.trig = trig + frame * npx; F.reg = reg + frame * npx;
     F.seedt = seedt + frame * npx; F.ring = s_ring; F.term = s_term; F.sctab = P.sctab; F.map = s_map;
+    F.interior = __ballot((lane & 7) >= 1 && (lane & 7) <= 6 && (lane >> 3) >= 1 && (lane >> 3) <= 6);
     const LsdgFast fcP = lsdg_fast_setup(P.prec);
+    LsdgPend pd;
+    pd.PA = 0ull; pd.pox = 0; pd.poy = 0;
     // (the used flags start at 0: k_lsd_grad has just written the records)
     (void)words;
     float* out = seg + (size_t)frame * P.maxseg * 4;
@@ -864,6 +949,8 @@ __global__ __launch_bounds__(64, PSL_GROW_WAVES) void k_lsd_grow3(LineParams P, 
         // pixels with a defined angle and of used pixels.  The seed loop below exists ONCE (not per row): the kernel's code is
         // dominated by the inlined region growing, and four copies of it did not fit the instruction cache.
         unsigned long long dm[4], um[4];
+        const int trip_end = min(base + 256, scan_end);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // marks of the last region's last round
         {
             float a4[4];
             uint32_t u4[4];
@@ -908,13 +995,15 @@ __global__ __launch_bounds__(64, PSL_GROW_WAVES) void k_lsd_grow3(LineParams P, 
                 const int adx = base + q * 64 + s;
                 const int y = adx / P.W, x = adx - y * P.W;
                 double reg_angle;
-                int reg_size = lsdg_region_grow4(F, x, y, &reg_angle, P.prec, fcP);
-                stale = true;
-                dirty = true;
+                bool touched = false;
+                int reg_size = lsdg_region_grow4(F, x, y, &reg_angle, P.prec, fcP, pd, false, trip_end, touched);
+                if (touched) { stale = true; dirty = true; }
                 if (reg_size < P.min_reg_size) continue;
                 LsdRect rec;
                 lsdw_region2rect(F, reg_size, reg_angle, P.prec, &rec);
-                if (!lsdw_refine(F, reg_size, reg_angle, P.prec, &rec, 0.7)) continue;
+                const int kept = lsdw_refine(F, reg_size, reg_angle, P.prec, &rec, 0.7, pd, trip_end, touched);
+                if (touched) { stale = true; dirty = true; }
+                if (!kept) continue;
                 if (count < P.maxseg && lane == 0) {
                     if (P.refine >= 2) {  // LSD_REFINE_ADV: the NFA validation never touches `used`, so it runs afterwards, one wave per rectangle
                         double* r = rects + ((size_t)frame * P.maxseg + count) * PSL_LSD_RECT_F64;
@@ -928,6 +1017,13 @@ __global__ __launch_bounds__(64, PSL_GROW_WAVES) void k_lsd_grow3(LineParams P, 
         }
     }
     if (lane == 0) nseg[frame] = count < P.maxseg ? count : P.maxseg;
+#ifdef PSL_GROW_STATS
+    if (frame == 0 && lane == 0) {
+        printf("grow stats: regions %llu rounds %llu pops %llu pops_with_cand %llu tests %llu amb %llu exact %llu bulk %llu accepted %llu\n", g_gstats[0], g_gstats[1],
+               g_gstats[2], g_gstats[3], g_gstats[4], g_gstats[5], g_gstats[6], g_gstats[7], g_gstats[8]);
+        for (int k = 0; k < 16; ++k) g_gstats[k] = 0;
+    }
+#endif
 }
 
 #endif

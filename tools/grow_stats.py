@@ -23,6 +23,9 @@ def growlog(img):
     regs = []
     p = 0
     while p < n:
+        if g[p] == -2:
+            print('  candidate tests (defined, not used):', g[p + 1])
+            break
         assert g[p] == -1
         m = g[p + 1]
         regs.append(g[p + 2:p + 2 + 3 * m].reshape(m, 3))
@@ -80,6 +83,6 @@ if __name__ == '__main__':
         sizes = np.array([len(r) for r in regs])
         print(kind, 'regions', len(regs), 'pixels', sizes.sum(), 'singles', (sizes == 1).sum(), '>=15:', (sizes >= 15).sum())
         print('  rounds current(7)', sum(rounds_batch(r) for r in regs))
-        for (wx, wy) in [(8, 8), (16, 8), (8, 16), (12, 12), (16, 16), (32, 32)]:
+        for (wx, wy) in [(8, 8)]:
             for place in ['down', 'away', 'corner']:
                 print('  window %2dx%-2d %-6s' % (wx, wy, place), sum(rounds_window(r, wx, wy, place) for r in regs))
