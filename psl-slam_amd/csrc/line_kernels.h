@@ -39,7 +39,7 @@ struct LineParams {
     double rho_q;             // largest q with sqrt(q) <= rho: `norm <= rho` decided on the squared magnitude
     int min_reg_size;
     const double* sctab;      // psl_sincostab.inc in HBM: the table of the glibc-exact double sin / cos (psl_sincos_glibc.h)
-    int refine;               // 1 = LSD_REFINE_STD (segments leave k_lsd_grow3), 2 = LSD_REFINE_ADV (rectangles -> k_lsd_nfa -> k_lsd_emit)
+    int refine;               // 1 = LSD_REFINE_STD (segments leave k_lsd_grow4), 2 = LSD_REFINE_ADV (rectangles -> k_lsd_nfa -> k_lsd_emit)
     double log_nt;            // LOG_NT of the NFA: 5 (log10 W + log10 H) / 2 + log10 11
     int full_grad;            // k_lsd_grad stores the gradient magnitude of every pixel (debug tap), not only where the angle is defined
     int lbdK[5];              // integer Gaussian 5x5 sigma 1 (OpenCV 3.2 8-bit path)
@@ -221,7 +221,7 @@ __device__ __forceinline__ bool psl_lsd_norm(const LineParams& P, const double* 
     return true;
 }
 
-// trig[o] = (cosf, sinf, angle in degrees | NOTDEF, used = 0): everything a round of k_lsd_grow3 needs of a neighbour in ONE
+// trig[o] = (cosf, sinf, angle in degrees | NOTDEF, used = 0): everything a round of k_lsd_grow4 needs of a neighbour in ONE
 // 16-byte record (a round touches 3-4 cache lines instead of ~10 in three arrays: the growing is bound by the latency of these
 // fetches); seedt[o] = (float)cos / sin of the double angle, read once per seed.  A record is only ever read for a pixel with a
 // defined angle (seed scan) or for a neighbour of one (growing), so it is written only for those - about a third of the pixels;
@@ -319,23 +319,30 @@ __device__ __forceinline__ double psl_lsd_density(int reg_size, const LsdRect& r
 
 // ---------------------------------------------------------------------------------------------
 // LSD steps 3-6: seeds in raster order, region growing (8-connected, running mean angle), rectangle by
-// inertia axes, density refinement - wave-parallel and still exact (k_lsd_grow3).  The algorithm is a serial
+// inertia axes, density refinement - wave-parallel and still exact (k_lsd_grow4).  The algorithm is a serial
 // chain through `used` and the running angle; one wave owns one frame and parallelism comes from the frames
 // of the batch.
-//  * seeds: 256 pixels per step (4 coalesced loads in flight), ballot -> first candidate;
-//  * region growing: up to 7 queue entries are popped together, lane = (entry, neighbour): the 63
-//    neighbour records are loaded in ONE round trip; only the running-angle chain (add, fastAtan2) stays
-//    serial, in the reference's order; the last 1024 queue entries are mirrored in an LDS ring;
+//  * seeds: 256 pixels per step (4 coalesced loads in flight), ballot -> first candidate; the `used` words of the step are looked
+//    at again only after a region that took pixels in front of the scan;
+//  * region growing: window rounds (lsdg_region_grow4 below) - the records of an 8 x 8 pixel window in ONE round trip, then queue
+//    entries are popped for as long as their neighbours are lanes of the wave; the running sums are added in the reference's order,
+//    decisions come from a rigorous cross / dot test and, within its margin, from the reference's own arithmetic; the last 1024 queue
+//    entries live in an LDS ring, older ones in HBM;
 //  * sums whose rounding depends on the order (centroid, inertia, refine statistics) are formed as
 //    "terms in parallel, additions in series" (64 terms staged in LDS per step); min/max extents are
 //    order independent and use wave reductions;
-//  * the `used` flag is the fourth word of the pixel's 16-byte record in HBM, written by lane 0 and read by
-//    the same wave only (workgroup scope: the CU's L1 is coherent for its own stores); inside a round every
-//    lane keeps its own "used" flag, updated by comparing its pixel with each pixel that is added.
-// Serial scalar logic is executed redundantly by all lanes (uniform values, no broadcasts); stores
-// are issued by lane 0.
+//  * the `used` flag is the fourth word of the pixel's 16-byte record in HBM, written and read by the same wave only (workgroup
+//    scope: the CU's L1 is coherent for its own stores); stores that may still be in flight when the next window is loaded are
+//    known from the previous round's acceptance mask instead of being waited for.
+// Wave-uniform logic runs on the scalar unit (masks, counters) or redundantly in all lanes (the float sums).
 // ---------------------------------------------------------------------------------------------
-#define PSL_LSD_RING 1024
+#ifndef PSL_LSD_RING
+#define PSL_LSD_RING 1024   // queue entries kept in LDS (a power of two >= 128).  A frontier that lags more than half of this behind the queue's end
+                            // does not occur on 8-bit images (the gradient threshold of 5.2 grey levels per pixel limits a region to ~50 pixels along
+                            // its gradient, hence the breadth-first frontier to ~100 entries): that path is exercised by building with
+                            // -DPSL_LSD_RING=128 and running tests/test_line_gpu.py (its "band" image reaches a lag of 85)
+#endif
+#define PSL_LSD_HALF (PSL_LSD_RING / 2)
 
 struct LsdW {
     int W, H, lane;
@@ -361,21 +368,6 @@ __device__ __forceinline__ bool lsdg_used(const LsdW& F, int a) {
 __device__ __forceinline__ void lsdg_mark(const LsdW& F, int a, uint32_t v) {
     __hip_atomic_store(reinterpret_cast<uint32_t*>(&F.trig[a].w), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
-// Queue push of k_lsd_grow3: the LDS ring is the queue; a block of 512 entries goes to HBM (coalesced, all lanes) when it is
-// complete, long before the ring wraps over it, so that lsdw_reg finds older entries there.  Called by all lanes.
-__device__ __forceinline__ void lsdg_push(const LsdW& F, int idx, uint32_t v, int cell) {
-    if (F.lane == 0) {
-        lsdg_mark(F, cell, 1);
-        F.ring[idx & (PSL_LSD_RING - 1)] = v;
-    }
-    if (((idx + 1) & 511) == 0) {
-        __builtin_amdgcn_wave_barrier();
-        const int b0 = idx + 1 - 512;
-#pragma unroll
-        for (int t = 0; t < 8; ++t) F.reg[b0 + t * 64 + F.lane] = F.ring[(b0 + t * 64 + F.lane) & (PSL_LSD_RING - 1)];
-    }
-}
-
 // |theta - ad| folded into [0, pi] and compared with prec, as lsdw_aligned but without branches: both differences are formed
 // and one is selected (the serial acceptance chain below executes this once per accepted pixel).
 __device__ __forceinline__ double lsdg_fold(double ad, double theta) {
@@ -384,124 +376,6 @@ __device__ __forceinline__ double lsdg_fold(double ad, double theta) {
     return d > (3 * PSL_PI) / 2 ? d2 : d;
 }
 __device__ __forceinline__ bool lsdg_aligned(double ad, double theta, double prec) { return lsdg_fold(ad, theta) <= prec; }
-// a lower bound of |(x, y)|: its projection on the direction pi/8 from the larger component (constants rounded down)
-__device__ __forceinline__ float lsdg_norm_lb(float x, float y) {
-    const float ax = __builtin_fabsf(x), ay = __builtin_fabsf(y);
-    return 0.9238f * fmaxf(ax, ay) + 0.3826f * fminf(ax, ay);
-}
-__device__ __forceinline__ double lsdg_angle(float sumdx, float sumdy) { return PSL_DMUL((double)psl_fast_atan2(sumdy, sumdx), PSL_DEG2RAD); }
-
-__device__ int lsdg_region_grow(const LsdW& F, int sx, int sy, double* reg_angle_out, double prec) {
-    int reg_size = 1;
-    const int addr0 = sx + sy * F.W;
-    lsdg_push(F, 0, (uint32_t)sx | ((uint32_t)sy << 16), addr0);
-    double reg_angle = PSL_DMUL((double)F.ang[addr0], PSL_DEG2RAD);
-    const float2 t0 = F.seedt[addr0];
-    float sumdx = t0.x, sumdy = t0.y;
-    float Mref = lsdg_norm_lb(sumdx, sumdy), invM = __builtin_amdgcn_rcpf(Mref);
-    int m_prior = 0;  // pixels added since reg_angle was computed from the sums
-    const int e = F.lane / 9, k = F.lane - e * 9, ky = k / 3, kx = k - ky * 3;
-    int i = 0;
-    while (i < reg_size) {
-        const int nb = min(7, reg_size - i);
-        // A round costs two memory round trips in series if it is written naively: wait for the marks of the previous round,
-        // then fetch the neighbours.  The angle and its cosine / sine do not depend on the marks, so they are requested FIRST
-        // (unconditionally: clamped address, so that exactly one vector-memory instruction follows the marks), then
-        // `s_waitcnt vmcnt(1)` - vector-memory operations complete in issue order on gfx9 - waits for everything older than that
-        // load, i.e. for every mark issued so far, and only the `used` word of the same record (same cache line) is read after it.
-        const bool mine = F.lane < 63 && e < nb;
-        const int qe = i + (mine ? e : 0);
-        // the queue entry comes from the LDS ring through an explicit LDS pointer: a select between the (generic) ring pointer
-        // and the HBM queue is compiled into ONE flat load, and the wait for a flat load also waits for the marks
-        typedef __attribute__((address_space(3))) const uint32_t lds_u32;
-        uint32_t rp = ((lds_u32*)F.ring)[qe & (PSL_LSD_RING - 1)];
-        if (reg_size - i > PSL_LSD_RING) {  // uniform, rare: blob regions whose frontier lags > 1024 entries
-            const uint32_t g = F.reg[qe];
-            asm volatile("v_mov_b32 %0, %1" : "=v"(rp) : "v"(g));  // consumed here, so that its wait is not placed after the join
-        }
-        const int nx = (int)(rp & 0xffff) + kx - 1, ny = (int)(rp >> 16) + ky - 1;
-        const bool inside = mine && nx >= 0 && nx < F.W && ny >= 0 && ny < F.H;
-        const int cidx = inside ? nx + ny * F.W : addr0;
-        const float3 t = *reinterpret_cast<const float3*>(&F.trig[cidx]);
-        asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-        const bool u = lsdg_used(F, cidx) || !inside;
-        const float cs = t.x, sn = t.y;
-        float a = t.z;
-        const uint32_t xy = inside ? ((uint32_t)nx | ((uint32_t)ny << 16)) : 0xffffffffu;
-        if (!inside) a = PSL_LSD_NOTDEF;
-        const double ad = PSL_DMUL((double)a, PSL_DEG2RAD);
-        // Lanes are ordered (entry, neighbour) exactly as the reference visits them; `live` = lanes that can still join in this
-        // round (defined angle, not used, behind the last decided lane, not a second copy of an accepted pixel).  The reference
-        // updates the region angle after EVERY accepted pixel (fastAtan2 of the running sums, ~37 instructions of a ~45
-        // instruction step) and tests the next neighbour against it.  Here the angle is brought up to date only when a decision
-        // needs it: `reg_angle` is exact for the sums at some earlier moment ("reference"), m_prior pixels have been added since,
-        // and a lane that at most n more live lanes precede is tested against an angle that differs from the reference one by
-        //   <= 2 eps + asin(x), x = 1.012 (m_prior + n) / |S_ref|;  asin x <= 1.048 x for x <= 0.5, <= (pi / 2) x always
-        //   (1.012: the added vectors have length 1 +- 2e-7 and every f32 addition to a sum of norm <= 2e5 rounds by <= 0.012);
-        //   the code uses 1.07 and 1.616 times (m_prior + n) / |S_ref|'s lower bound, i.e. 1 % beyond 1.048 * 1.012 and pi / 2 * 1.012;
-        //   |S_ref| >= 0.9238 max(|sumdx|, |sumdy|) + 0.3826 min(|sumdx|, |sumdy|) (its projection on the direction pi / 8)
-        // (eps: error of the fastAtan2 polynomial, measured 0.0095 deg, taken as 0.05 deg; unit vectors added to a sum S turn it
-        // by at most asin(|added| / |S|); the region's sum never shrinks below 1 because every added vector
-        // is within 22.5 deg of it).  The folded difference is 1-Lipschitz in the angle, so a lane whose difference to the
-        // reference angle is below prec - delta joins, above prec + delta does not, whatever the exact angle is; the first lane
-        // in between stops the batch, the angle is recomputed from the sums (exactly what the reference holds there) and that lane
-        // is decided as before.  Sums are added in lane order, so all results are bit-identical; on clean edges one fastAtan2
-        // serves several pixels.
-        unsigned long long live = __ballot(a != PSL_LSD_NOTDEF && !u);
-        if (live && (float)(4 * m_prior) > Mref) {  // keep the drift bound useful
-            reg_angle = lsdg_angle(sumdx, sumdy);
-            Mref = lsdg_norm_lb(sumdx, sumdy); invM = __builtin_amdgcn_rcpf(Mref); m_prior = 0;
-        }
-        while (live) {
-            const double r = lsdg_fold(ad, reg_angle);
-            const int nbef = __builtin_amdgcn_mbcnt_hi((uint32_t)(live >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)live, 0u));
-            const float ratio = (float)(m_prior + nbef) * invM;
-            const float delta = ratio <= 0.49f ? (0.002f + 1.06f * ratio) * 1.01f : (ratio <= 0.9f ? (0.002f + 1.6f * ratio) * 1.01f : 10.0f);
-            const unsigned long long RA = __ballot(r <= prec - (double)delta) & live;
-            const unsigned long long RN = __ballot(r >= prec + (double)delta);
-            const unsigned long long amb = live & ~RA & ~RN;
-            const unsigned long long below = amb ? ((amb & (0ull - amb)) - 1ull) : ~0ull;  // lanes in front of the first undecided one
-            unsigned long long acc = RA & below;
-            live &= ~below;
-            while (acc) {
-                const int L = __ffsll((long long)acc) - 1;  // wave-uniform: v_readlane instead of ds_bpermute
-                const uint32_t xyL = (uint32_t)__builtin_amdgcn_readlane((int)xy, L);
-                const int cL = __builtin_amdgcn_readlane(cidx, L);
-                const float csL = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cs), L));
-                const float snL = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sn), L));
-                const unsigned long long dup = __ballot(xy == xyL);  // this lane and the other copies of its pixel
-                acc &= ~dup; live &= ~dup;
-                lsdg_push(F, reg_size, xyL, cL);
-                ++reg_size; ++m_prior;
-                sumdx = PSL_FADD(sumdx, csL);
-                sumdy = PSL_FADD(sumdy, snL);
-            }
-            if (!live) break;
-            if (m_prior) {
-                reg_angle = lsdg_angle(sumdx, sumdy);
-                Mref = lsdg_norm_lb(sumdx, sumdy); invM = __builtin_amdgcn_rcpf(Mref); m_prior = 0;
-            }
-            const unsigned long long m1 = __ballot(lsdg_aligned(ad, reg_angle, prec)) & live;
-            if (!m1) break;  // the angle is exact and does not change without a new pixel: nobody else joins in this round
-            const int L = __ffsll((long long)m1) - 1;
-            const uint32_t xyL = (uint32_t)__builtin_amdgcn_readlane((int)xy, L);
-            const int cL = __builtin_amdgcn_readlane(cidx, L);
-            const float csL = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cs), L));
-            const float snL = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sn), L));
-            live &= ~((2ull << L) - 1ull) & ~__ballot(xy == xyL);
-            lsdg_push(F, reg_size, xyL, cL);
-            ++reg_size; m_prior = 1;
-            sumdx = PSL_FADD(sumdx, csL);
-            sumdy = PSL_FADD(sumdy, snL);
-        }
-        i += nb;
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (m_prior) reg_angle = lsdg_angle(sumdx, sumdy);
-    *reg_angle_out = reg_angle;
-    return reg_size;
-}
-
 // ---------------------------------------------------------------------------------------------
 // Region growing in WINDOW ROUNDS.  The queue order of the reference (breadth first, 3 x 3 neighbours in raster order, the
 // region angle brought up to date after every pixel) is kept exactly; what changes is how much of it one memory round trip serves.
@@ -535,6 +409,11 @@ __device__ unsigned long long g_gstats[16];
 #else
 #define GS(k)
 #endif
+// a wave-uniform 64-bit value the compiler no longer knows to be uniform (after inline asm / volatile reloads): back into SGPRs
+__device__ __forceinline__ unsigned long long lsdg_uniform64(unsigned long long v) {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+}
 struct LsdgFast { float t_hi, t_lo; int ok; };
 __device__ __forceinline__ LsdgFast lsdg_fast_setup(double prec) {
     LsdgFast f;
@@ -554,9 +433,10 @@ struct LsdgPend { unsigned long long PA; int pox, poy; };
 // rejects against the current sums unless still valid (`fresh`), skip the sure rejects in front, take the first other candidate c:
 // a sure join is added (sums in order, its queue index, `live`), anything else ends the block with c returned (it is removed from
 // cand; the caller runs the reference's arithmetic for it).  Returns -1 when all candidates are decided.
-// gfx950 wait states observed: a VALU-written SGPR / VCC is read by a VALU instruction no sooner than the third instruction after it.
+// gfx950 wait states observed: an SGPR written by a VALU instruction (v_readlane) is read by a VALU instruction no sooner than the third
+// instruction after it.
 __device__ __forceinline__ int lsdg_decide(unsigned long long& cand, unsigned long long& live, unsigned long long& RA, unsigned long long& RN, int& fresh,
-                                           int& reg_size, float& sumdx, float& sumdy, int& seq, float cs, float sn, int lane, float t_hi, float t_lo) {
+                                           int& reg_size, float& sumdx, float& sumdy, int& seq, float cs, float sn, float t_hi, float t_lo) {
     int cx, c, sa, sb;
     float t0, t1, t2;
     unsigned long long tm;
@@ -583,13 +463,13 @@ __device__ __forceinline__ int lsdg_decide(unsigned long long& cand, unsigned lo
         "s_and_b64 %[cand], %[cand], %[tm]\n\t"
         "s_bitcmp1_b64 %[RA], %[c]\n\t"
         "s_cbranch_scc0 .Lamb%=\n\t"
+        "s_mov_b32 m0, %[c]\n\t"
         "v_readlane_b32 %[sa], %[cs], %[c]\n\t"
         "v_readlane_b32 %[sb], %[sn], %[c]\n\t"
-        "v_cmp_eq_u32 vcc, %[c], %[lane]\n\t"
-        "v_mov_b32 %[t0], %[rs]\n\t"
+        "v_writelane_b32 %[seq], %[rs], m0\n\t"
+        "s_nop 0\n\t"
         "v_add_f32 %[sx], %[sa], %[sx]\n\t"
         "v_add_f32 %[sy], %[sb], %[sy]\n\t"
-        "v_cndmask_b32 %[seq], %[seq], %[t0], vcc\n\t"
         "s_bitset0_b64 %[live], %[c]\n\t"
         "s_add_i32 %[rs], %[rs], 1\n\t"
         "s_mov_b32 %[fresh], 0\n\t"
@@ -604,8 +484,8 @@ __device__ __forceinline__ int lsdg_decide(unsigned long long& cand, unsigned lo
         ".Ldone%=:\n\t"
         : [cand] "+s"(cand), [live] "+s"(live), [RA] "+s"(RA), [RN] "+s"(RN), [fresh] "+s"(fresh), [rs] "+s"(reg_size), [sx] "+v"(sumdx), [sy] "+v"(sumdy),
           [seq] "+v"(seq), [cx] "=&s"(cx), [c] "=&s"(c), [sa] "=&s"(sa), [sb] "=&s"(sb), [tm] "=&s"(tm), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2)
-        : [cs] "v"(cs), [sn] "v"(sn), [lane] "v"(lane), [thi] "v"(t_hi), [tlo] "v"(t_lo)
-        : "vcc", "scc");
+        : [cs] "v"(cs), [sn] "v"(sn), [thi] "v"(t_hi), [tlo] "v"(t_lo)
+        : "scc", "m0");
     return cx;
 }
 
@@ -643,8 +523,10 @@ __device__ int lsdg_region_grow4(const LsdW& F, int sx, int sy, double* reg_angl
         GS(1);
         const int qi = i + lane;
         uint32_t q = 0xffffffffu;
-        if (reg_size - i > PSL_LSD_RING) {  // uniform, rare: the frontier lags > 1024 entries; these have been flushed to HBM
-            if (qi < reg_size - PSL_LSD_RING / 2) {
+        if (reg_size - i > PSL_LSD_HALF) {  // uniform: the frontier lags more than half a ring behind the queue's end: the entries in front of
+            // the last half ring have been flushed to HBM and are mapped from there (the younger ones are reached in a later round)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the flush may be the previous round's
+            if (qi < reg_size - PSL_LSD_HALF) {
                 const uint32_t g = F.reg[qi];
                 asm volatile("v_mov_b32 %0, %1" : "=v"(q) : "v"(g));
             }
@@ -683,7 +565,7 @@ __device__ int lsdg_region_grow4(const LsdW& F, int sx, int sy, double* reg_angl
             if (cand) GS(3);
             while (cand) {
                 GS(4);
-                const int c = lsdg_decide(cand, live, RA, RN, fresh, reg_size, sumdx, sumdy, seq, cs, sn, lane, fc.t_hi, fc.t_lo);
+                const int c = lsdg_decide(cand, live, RA, RN, fresh, reg_size, sumdx, sumdy, seq, cs, sn, fc.t_hi, fc.t_lo);
                 if (c < 0) break;
                 // lane c is within the margin of the threshold: the reference's arithmetic
                 GS(6);
@@ -705,11 +587,11 @@ __device__ int lsdg_region_grow4(const LsdW& F, int sx, int sy, double* reg_angl
             lsdg_mark(F, cidx, 1);
         }
         if (__ballot(seq >= rs0 && cidx > addr0 && cidx < trip_end)) touched = true;
-        if ((reg_size >> 9) != (rs0 >> 9)) {  // a block of 512 entries is complete: to HBM, long before the ring wraps over it
+        if (reg_size / PSL_LSD_HALF != rs0 / PSL_LSD_HALF) {  // half a ring of entries is complete: to HBM, long before the ring wraps over it
             __builtin_amdgcn_wave_barrier();
-            const int b0 = ((reg_size >> 9) - 1) << 9;
+            const int b0 = (reg_size / PSL_LSD_HALF - 1) * PSL_LSD_HALF;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) F.reg[b0 + k * 64 + lane] = ring[(b0 + k * 64 + lane) & (PSL_LSD_RING - 1)];
+            for (int k = 0; k < PSL_LSD_HALF / 64; ++k) F.reg[b0 + k * 64 + lane] = ring[(b0 + k * 64 + lane) & (PSL_LSD_RING - 1)];
         }
         PA = acc_round; pox = ox; poy = oy;
         first = false;
@@ -901,7 +783,7 @@ __device__ int lsdw_refine(const LsdW& F, int reg_size, double reg_angle, double
     return reg_size;
 }
 
-#define PSL_LSD_RECT_F64 12  // doubles per rectangle record handed to the NFA kernels: x1 y1 x2 y2 width theta dx dy (k_lsd_grow3) | prec p log_nfa pad
+#define PSL_LSD_RECT_F64 12  // doubles per rectangle record handed to the NFA kernels: x1 y1 x2 y2 width theta dx dy (k_lsd_grow4) | prec p log_nfa pad
 
 // flsd()'s output step (+0.5, / SCALE, to float) followed by the contrib wrapper's checkLineExtremes
 // (Thirdparty/line_descriptor/src/LSDDetector_custom.cpp:111-138)
@@ -919,10 +801,10 @@ __device__ __forceinline__ void psl_lsd_store_segment(const LineParams& P, doubl
 }
 
 #ifndef PSL_GROW_WAVES
-#define PSL_GROW_WAVES 6   // waves per SIMD the register budget allows: 6 (80 VGPRs, a few spills) with 6144 frames in flight is
-                           // 9 % faster per frame than 5 with 4096-5120; 7 (72 VGPRs, 18 spills) gains nothing more
+#define PSL_GROW_WAVES 6   // waves per SIMD: measured on 12288 frames (tools/occ_sweep.sh) 5: 60.5 ms, 6: 52.1 ms, 7: 53.4 ms (72 VGPRs, more spills);
+                           // without a bound the kernel takes 105 VGPRs (4 waves): 63.1 ms
 #endif
-__global__ __launch_bounds__(64, PSL_GROW_WAVES) void k_lsd_grow3(LineParams P, const float* __restrict__ angdeg, const double* __restrict__ modgrad,
+__global__ __launch_bounds__(64, PSL_GROW_WAVES) void k_lsd_grow4(LineParams P, const float* __restrict__ angdeg, const double* __restrict__ modgrad,
                                                    float4* __restrict__ trig, const float2* __restrict__ seedt, uint32_t* __restrict__ reg,
                                                    float* __restrict__ seg, int* __restrict__ nseg, double* __restrict__ rects) {
     __shared__ uint32_t s_ring[PSL_LSD_RING];
@@ -939,12 +821,17 @@ __global__ __launch_bounds__(64, PSL_GROW_WAVES) void k_lsd_grow3(LineParams P, 
     const LsdgFast fcP = lsdg_fast_setup(P.prec);
     LsdgPend pd;
     pd.PA = 0ull; pd.pox = 0; pd.poy = 0;
+#ifdef PSL_GROW_STATS
+    const unsigned long long st_c0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
     // (the used flags start at 0: k_lsd_grad has just written the records)
     (void)words;
     float* out = seg + (size_t)frame * P.maxseg * 4;
     int count = 0;
     const int scan_end = (P.H - 1) * P.W;
-    for (int base = 0; base < scan_end; base += 256) {
+    int trip_x = 0, trip_y = 0;  // (x, y) of pixel `base`, kept without divisions
+    for (int base = 0; base < scan_end; base += 256, trip_x += 256) {
+        while (trip_x >= P.W) { trip_x -= P.W; ++trip_y; }
         // four 64-pixel rows per trip, their loads in flight together; what is kept of them is wave-uniform: the masks of
         // pixels with a defined angle and of used pixels.  The seed loop below exists ONCE (not per row): the kernel's code is
         // dominated by the inlined region growing, and four copies of it did not fit the instruction cache.
@@ -990,10 +877,11 @@ __global__ __launch_bounds__(64, PSL_GROW_WAVES) void k_lsd_grow3(LineParams P, 
                     dirty = false;
                     if (!mask) break;
                 }
+                mask = lsdg_uniform64(mask);
                 const int s = __ffsll((long long)mask) - 1;
                 mask &= mask - 1;
-                const int adx = base + q * 64 + s;
-                const int y = adx / P.W, x = adx - y * P.W;
+                int x = trip_x + q * 64 + s, y = trip_y;
+                while (x >= P.W) { x -= P.W; ++y; }
                 double reg_angle;
                 bool touched = false;
                 int reg_size = lsdg_region_grow4(F, x, y, &reg_angle, P.prec, fcP, pd, false, trip_end, touched);
@@ -1019,8 +907,10 @@ __global__ __launch_bounds__(64, PSL_GROW_WAVES) void k_lsd_grow3(LineParams P, 
     if (lane == 0) nseg[frame] = count < P.maxseg ? count : P.maxseg;
 #ifdef PSL_GROW_STATS
     if (frame == 0 && lane == 0) {
-        printf("grow stats: regions %llu rounds %llu pops %llu pops_with_cand %llu tests %llu amb %llu exact %llu bulk %llu accepted %llu\n", g_gstats[0], g_gstats[1],
-               g_gstats[2], g_gstats[3], g_gstats[4], g_gstats[5], g_gstats[6], g_gstats[7], g_gstats[8]);
+        const unsigned long long dc = __builtin_amdgcn_s_memtime() - st_c0, dr = __builtin_amdgcn_s_memrealtime() - st_r0;
+        printf("grow clock: %llu shader cycles in %llu ticks of 100 MHz = %.0f MHz\n", dc, dr, (double)dc / (double)dr * 100.0);
+        printf("grow stats: regions %llu rounds %llu pops %llu pops_with_candidates %llu decision_blocks %llu exact_tests %llu\n", g_gstats[0], g_gstats[1],
+               g_gstats[2], g_gstats[3], g_gstats[4], g_gstats[6]);
         for (int k = 0; k < 16; ++k) g_gstats[k] = 0;
     }
 #endif

@@ -5,7 +5,7 @@
 // nfa() / log_gamma() arithmetic has a twin there: Thirdparty/line_descriptor/src/ED_Lib/NFA.cpp:106-240.
 //
 // Decomposition.  The validation reads the level-line angles and the rectangle, never the `used` map, and a
-// rejected rectangle releases nothing: it does not feed back into the region growing.  k_lsd_grow3 therefore only
+// rejected rectangle releases nothing: it does not feed back into the region growing.  k_lsd_grow4 therefore only
 // records the rectangles (in seed order) and this file validates them afterwards with ONE WAVE PER RECTANGLE -
 // thousands of independent waves per launch instead of a longer serial chain per frame:
 //   k_lsd_nfa_count / k_lsd_nfa_eval  one pair of launches per rect_improve phase (see below): pixel scans with one wave per

@@ -35,7 +35,7 @@ struct pslfe_line {
     LsdnTables NT = {};           // LSD_REFINE_ADV: log_gamma / log(p) tables of nfa() (NT.lg in HBM)
     double* d_lgamma = nullptr;
     double* d_sctab = nullptr;    // psl_sincostab.inc
-    double* d_rects = nullptr;    // LSD_REFINE_ADV: rectangles of k_lsd_grow3 for k_lsd_nfa
+    double* d_rects = nullptr;    // LSD_REFINE_ADV: rectangles of k_lsd_grow4 for k_lsd_nfa
     int* d_nrect = nullptr;
     float* d_segtmp = nullptr;
     uint8_t* d_keep = nullptr;
@@ -252,7 +252,7 @@ struct pslfe_line {
         {
             PSL_STAGE_BEGIN(ctx, "line.lsd_grow");
             // LSD_REFINE_ADV: the kernel leaves rectangles (d_rects / d_nrect) for the NFA validation below
-            k_lsd_grow3<<<F, 64, 0, st>>>(P, d_angdeg, d_modgrad, d_trig, d_seedt, d_reg, d_seg, refine >= 2 ? d_nrect : d_nseg, d_rects);
+            k_lsd_grow4<<<F, 64, 0, st>>>(P, d_angdeg, d_modgrad, d_trig, d_seedt, d_reg, d_seg, refine >= 2 ? d_nrect : d_nseg, d_rects);
             PSL_STAGE_END(ctx, "line.lsd_grow");
         }
         if (refine >= 2) {

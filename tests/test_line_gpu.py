@@ -126,6 +126,48 @@ def test_lsd_large_regions_exercise_queue_overflow():
         assert len(ref) >= (4 if mode == STD else 2) and exact
 
 
+def _adversarial_images():
+    """Inputs that stress the queue order of the region growing rather than look like a room: rings (regions that turn and close on
+    themselves), stripes of every thickness in both diagonals (frontiers several entries wide, growth up and to the left of the seed),
+    smoothed noise (blobs, many tiny regions), a checker board (corners everywhere), raw noise, and a frame that touches all four
+    borders."""
+    import synth_frames as sf
+    h, w = 300, 400
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+    out = {}
+    r = np.hypot(xx - 190.3, yy - 140.7)
+    out["rings"] = np.clip(128 + 100 * np.sin(r / 3.1), 0, 255).astype(np.uint8)
+    st = np.zeros((h, w))
+    for k, (t, s) in enumerate([(1, 1), (2, -1), (3, 1), (5, -1), (8, 1), (13, -1)]):
+        d = (xx + s * yy * (0.35 + 0.2 * k)) - (40 + 55 * k) - (0 if s > 0 else -120)
+        st += 170.0 * (np.abs(d) < t)
+    out["stripes"] = np.clip(30 + st, 0, 255).astype(np.uint8)
+    out["blobs"] = sf.random_gray(w, h, 12, "blobs")
+    out["checker"] = sf.random_gray(w, h, 13, "checker")
+    out["noise"] = sf.random_gray(w, h, 14, "noise")
+    fr = np.full((h, w), 60, np.uint8)
+    fr[:3] = 250; fr[-3:] = 250; fr[:, :3] = 250; fr[:, -3:] = 250
+    fr[40:44, :] = 200; fr[:, 100:103] = 10
+    out["frame"] = fr
+    # one region of 22 000 pixels whose breadth-first frontier is 85 entries behind the queue's end (tools/grow_stats.py): the queue's
+    # LDS ring wraps 20 times; in a build with -DPSL_LSD_RING=128 the frontier is mapped from the HBM copy of the queue
+    by, bx = np.mgrid[0:200, 0:640].astype(np.float64)
+    out["band"] = np.rint(np.clip(4.4 * (by - 40 + 0.05 * np.abs(bx - 320)), 0, 255)).astype(np.uint8)
+    return out
+
+
+@pytest.mark.parametrize("refine_mode", [ADV, STD], indirect=True)
+def test_lsd_adversarial_queue_orders(refine_mode):
+    import oracle_lib
+    for name, img in _adversarial_images().items():
+        img = np.ascontiguousarray(img)
+        ref = oracle_lib.lsd_detect(img)
+        got = _extractor(refine_mode).lsd_detect(img)
+        exact = got.shape == ref.shape and (got.view(np.uint32) == ref.view(np.uint32)).all()
+        print(f"LSD {name} refine {refine_mode}: {len(got)} vs oracle {len(ref)} segments, bit-identical {exact}")
+        assert exact, name
+
+
 def test_lsd_flat_image_gives_no_segments():
     import psl_slam_amd as P
     assert len(P.LINEextractor().lsd_detect(np.full((480, 640), 128, np.uint8))) == 0

@@ -118,9 +118,9 @@ def test_seed_cos_sin_of_k_lsd_grad_equals_libm_for_every_float_angle(tmp_path):
 
 
 def test_fast_atan2_error_bound_used_by_the_lazy_region_angle():
-    """k_lsd_grow3 decides most neighbours of a growing region against an angle that is not up to date, using a bound on its
-    drift that contains 2 * eps, eps = the error of the fastAtan2 polynomial, taken as 0.05 degrees (line_kernels.h).  The
-    polynomial's error against atan2 is measured here: < 0.02 degrees on vectors of every direction and of the magnitudes a
+    """k_lsd_grow4 decides most neighbours of a growing region from the running sum itself instead of the reference's
+    fastAtan2(sum); its margin of 2e-3 rad (0.115 degrees, line_kernels.h) has to cover the error of the fastAtan2 polynomial.
+    The polynomial's error against atan2 is measured here: < 0.02 degrees on vectors of every direction and of the magnitudes a
     region's sum can have (>= 1)."""
     L = oracle_lib.load()
     L.pso_fast_atan2_f.restype = C.c_float
@@ -150,3 +150,52 @@ def test_restated_atanf_atan2f_equal_libm(tmp_path):
     for mode in ("0", "1"):
         out = subprocess.run([exe, mode], capture_output=True, text=True, timeout=900)
         assert out.returncode == 0 and "mismatches 0" in out.stdout, out.stdout
+
+
+def test_cross_dot_test_of_the_window_rounds_never_contradicts_the_reference_decision():
+    """k_lsd_grow4 decides a neighbour from the running sum S and the pixel's unit vector u: |S x u| < tan(prec - m) max(S.u, 0) => joins,
+    |S x u| >= tan(prec + m) max(S.u, 0) => does not (m = 2e-3 rad, line_kernels.h lsdg_fast_setup / lsdg_decide); everything in between
+    takes the reference's arithmetic.  Here the rule is evaluated in float32 on vectors of every direction, of the magnitudes a region's
+    sum can have, with the pixel angle placed around the threshold, for the detector's tolerance and for refinement tolerances, and
+    compared with the reference's decision fold(|fastAtan2(S) - a|) <= prec: a sure answer must never differ from it."""
+    L = oracle_lib.load()
+    L.pso_fast_atan2_f.restype = C.c_float
+    L.pso_fast_atan2_f.argtypes = [C.c_float, C.c_float]
+    rng = np.random.default_rng(11)
+    f32 = np.float32
+    K = np.pi / 180.0
+    m = f32(2.0e-3)
+    sure = 0
+    for prec in (np.pi * 22.5 / 180.0, 1.0e-3, 0.05, 0.2, 0.8, 1.2, 1.49, 1.6):
+        p = f32(prec)
+        ok = bool(p + m < f32(1.5))
+        t_hi = f32(np.tan(f32(p - m), dtype=f32) * f32(1 - 1e-5)) if ok and p - m > 0 else f32(-1)
+        t_lo = f32(np.tan(f32(p + m), dtype=f32) * f32(1 + 1e-5)) if ok else f32(np.inf)
+        n = 6000
+        th = rng.uniform(0, 360, n)
+        mag = np.exp(rng.uniform(np.log(0.93), np.log(2.0e5), n))
+        sx = (np.cos(th * K) * mag).astype(f32)
+        sy = (np.sin(th * K) * mag).astype(f32)
+        # pixel angles: around +-prec of the sum's direction (three widths), and anywhere
+        off = np.degrees(prec) * rng.choice([-1.0, 1.0], n) + np.where(rng.random(n) < 0.5, rng.normal(0, 0.05, n), rng.normal(0, 0.5, n))
+        a = np.where(rng.random(n) < 0.8, th + off, rng.uniform(0, 360, n)) % 360.0
+        a = a.astype(f32)
+        ar = (a.astype(np.float64) * K).astype(f32)
+        cs, sn = np.cos(ar, dtype=f32), np.sin(ar, dtype=f32)
+        dot = (sx * cs + sy * sn).astype(f32)
+        cr = np.abs((sx * sn - sy * cs).astype(f32))
+        dp = np.maximum(dot, f32(0))
+        with np.errstate(invalid="ignore"):
+            RA = cr < t_hi * dp
+            RN = cr >= t_lo * dp
+        reg = np.array([L.pso_fast_atan2_f(float(y), float(x)) for x, y in zip(sx, sy)], np.float64) * K
+        d = np.abs(reg - a.astype(np.float64) * K)
+        d = np.where(d > 1.5 * np.pi, np.abs(d - 2 * np.pi), d)
+        exact = d <= prec
+        assert not np.any(RA & RN)
+        assert not np.any(RA & ~exact), (prec, np.flatnonzero(RA & ~exact)[:5])
+        assert not np.any(RN & exact), (prec, np.flatnonzero(RN & exact)[:5])
+        if not ok:
+            assert not RA.any() and not RN.any()
+        sure += int(RA.sum() + RN.sum())
+    assert sure > 20000  # the rule decides most cases; the rest goes to the exact path

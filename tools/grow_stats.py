@@ -14,7 +14,7 @@ import synth_frames as sf
 
 def growlog(img):
     L = ol.load()
-    cap = 1 << 24
+    cap = 1 << 27
     out = np.empty(cap, np.int32)
     L.pso_lsd_growlog.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
     n = L.pso_lsd_growlog(img.ctypes.data, img.shape[1], img.shape[0], img.strides[0], out.ctypes.data, cap)
