@@ -221,14 +221,14 @@ __device__ __forceinline__ bool psl_lsd_norm(const LineParams& P, const double* 
     return true;
 }
 
-// trig[o] = (cosf, sinf, angle in degrees | NOTDEF, used = 0): everything a round of k_lsd_grow4 needs of a neighbour in ONE
-// 16-byte record (a round touches 3-4 cache lines instead of ~10 in three arrays: the growing is bound by the latency of these
-// fetches); seedt[o] = (float)cos / sin of the double angle, read once per seed.  A record is only ever read for a pixel with a
-// defined angle (seed scan) or for a neighbour of one (growing), so it is written only for those - about a third of the pixels;
-// 16 B for every pixel made this kernel HBM-write-bound (9.4 - 11.5 ms, varying between runs).  Which pixels have a defined
-// neighbour is known from a flag tile in LDS: 64 x 16 pixels per workgroup plus a one-pixel ring whose magnitudes are recomputed.
+// trig[o] = (cosf, sinf) of the pixel's angle, (0, 0) where the angle is undefined: what a round of k_lsd_grow4 needs of a neighbour
+// (the angle itself only inside the margin of the decision, read from angdeg then); seedt[o] = (float)cos / sin of the double
+// angle, read once per seed.  A record is only ever read for a pixel with a defined angle or for a neighbour of one, so it is written
+// only for those - about a third of the pixels (16-byte records for every pixel made this kernel HBM-write-bound, 9.4 - 11.5 ms).
+// Which pixels have a defined neighbour is known from a flag tile in LDS: 64 x 16 pixels per workgroup plus a one-pixel ring whose
+// magnitudes are recomputed.  8-byte records: a window row of the growing is 64 bytes, 1 - 2 HBM sectors instead of 2 - 3.
 __global__ __launch_bounds__(256) void k_lsd_grad(LineParams P, const double* __restrict__ scaled, float* __restrict__ angdeg,
-                                                   double* __restrict__ modgrad, float4* __restrict__ trig, float2* __restrict__ seedt) {
+                                                   double* __restrict__ modgrad, float2* __restrict__ trig, float2* __restrict__ seedt) {
     __shared__ uint8_t s_def[PSL_GRAD_TH + 2][68];
     const int frame = blockIdx.z, tid = threadIdx.x;
     const int x0 = blockIdx.x * 64, y0 = blockIdx.y * PSL_GRAD_TH;
@@ -295,7 +295,7 @@ __global__ __launch_bounds__(256) void k_lsd_grad(LineParams P, const double* __
         const uint8_t* d1 = &s_def[r + 1][tx];
         const uint8_t* d2 = &s_def[r + 2][tx];
         const bool any = (d0[0] | d0[1] | d0[2] | d1[0] | d1[1] | d1[2] | d2[0] | d2[1] | d2[2]) != 0;
-        if (any) trig[fo + (size_t)y * P.W + x] = make_float4(cs[i], sn[i], dg[i], 0);
+        if (any) trig[fo + (size_t)y * P.W + x] = make_float2(cs[i], sn[i]);
     }
 }
 
@@ -348,7 +348,8 @@ struct LsdW {
     int W, H, lane;
     const float* ang;
     const double* mod;
-    float4* trig;          // (cosf, sinf, degrees | NOTDEF, used flag) per pixel
+    const float2* trig;    // (cosf, sinf) per pixel, (0, 0) = angle undefined
+    uint8_t* used;         // the reference's `used` map, one byte per pixel
     const float2* seedt;   // (float)cos, (float)sin of the double angle (seed pixels)
     const double* sctab;
     uint32_t* ring;   // LDS mirror of reg[idx & (RING-1)]
@@ -363,11 +364,12 @@ __device__ __forceinline__ uint32_t lsdw_reg(const LsdW& F, int idx, int reg_siz
 }
 
 __device__ __forceinline__ bool lsdg_used(const LsdW& F, int a) {
-    return __hip_atomic_load(reinterpret_cast<const uint32_t*>(&F.trig[a].w), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0;
+    return __hip_atomic_load(F.used + a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0;
 }
-__device__ __forceinline__ void lsdg_mark(const LsdW& F, int a, uint32_t v) {
-    __hip_atomic_store(reinterpret_cast<uint32_t*>(&F.trig[a].w), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+__device__ __forceinline__ void lsdg_mark(const LsdW& F, int a, uint8_t v) {
+    __hip_atomic_store(F.used + a, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
+
 // |theta - ad| folded into [0, pi] and compared with prec, as lsdw_aligned but without branches: both differences are formed
 // and one is selected (the serial acceptance chain below executes this once per accepted pixel).
 __device__ __forceinline__ double lsdg_fold(double ad, double theta) {
@@ -538,7 +540,8 @@ __device__ int lsdg_region_grow4(const LsdW& F, int sx, int sy, double* reg_angl
         const int x = ox + lx, y = oy + ly;
         const bool inside = (unsigned)x < (unsigned)F.W && (unsigned)y < (unsigned)F.H;
         const int cidx = inside ? x + y * F.W : addr0;
-        const float4 t = F.trig[cidx];
+        const float2 t = F.trig[cidx];
+        const bool ub = lsdg_used(F, cidx);
         // queue entry -> lane of the window (while the load is in flight)
         const int qx = (int)(q & 0xffff) - ox, qy = (int)(q >> 16) - oy;
         map[lane] = 0u;
@@ -550,9 +553,9 @@ __device__ int lsdg_region_grow4(const LsdW& F, int sx, int sy, double* reg_angl
         const bool pa = (unsigned)px < 8u && (unsigned)py < 8u && ((PA >> (py * 8 + px)) & 1ull) != 0ull;
         const uint32_t xy = (uint32_t)x | ((uint32_t)y << 16);
         if (first) { sumdx = t0.x; sumdy = t0.y; }
-        const float cs = t.x, sn = t.y, a = t.z;
+        const float cs = t.x, sn = t.y;
         // a lane that holds a queue entry is a pixel of the region (the seed among them: its mark is not in memory yet)
-        unsigned long long live = __ballot(inside && a != PSL_LSD_NOTDEF && __float_as_uint(t.w) == 0u && !pa && seq < 0);
+        unsigned long long live = __ballot(inside && (cs != 0.f || sn != 0.f) && !ub && !pa && seq < 0);
         unsigned long long RA = 0ull, RN = 0ull;  // valid while the sums are the ones they were computed from (`fresh`)
         int fresh = 0;
         for (;;) {
@@ -570,7 +573,7 @@ __device__ int lsdg_region_grow4(const LsdW& F, int sx, int sy, double* reg_angl
                 // lane c is within the margin of the threshold: the reference's arithmetic
                 GS(6);
                 if (rs_angle != reg_size) { reg_deg = psl_fast_atan2(sumdy, sumdx); rs_angle = reg_size; }
-                const double ad = PSL_DMUL((double)a, PSL_DEG2RAD), th = PSL_DMUL((double)reg_deg, PSL_DEG2RAD);
+                const double ad = PSL_DMUL((double)F.ang[cidx], PSL_DEG2RAD), th = PSL_DMUL((double)reg_deg, PSL_DEG2RAD);
                 if (!((__ballot(lsdg_aligned(ad, th, prec)) >> c) & 1ull)) continue;
                 sumdx = PSL_FADD(sumdx, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cs), c)));
                 sumdy = PSL_FADD(sumdy, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sn), c)));
@@ -805,7 +808,7 @@ __device__ __forceinline__ void psl_lsd_store_segment(const LineParams& P, doubl
                            // without a bound the kernel takes 105 VGPRs (4 waves): 63.1 ms
 #endif
 __global__ __launch_bounds__(64, PSL_GROW_WAVES) void k_lsd_grow4(LineParams P, const float* __restrict__ angdeg, const double* __restrict__ modgrad,
-                                                   float4* __restrict__ trig, const float2* __restrict__ seedt, uint32_t* __restrict__ reg,
+                                                   const float2* __restrict__ trig, uint8_t* __restrict__ used, const float2* __restrict__ seedt, uint32_t* __restrict__ reg,
                                                    float* __restrict__ seg, int* __restrict__ nseg, double* __restrict__ rects) {
     __shared__ uint32_t s_ring[PSL_LSD_RING];
     __shared__ double s_term[3 * 64];
@@ -815,7 +818,7 @@ __global__ __launch_bounds__(64, PSL_GROW_WAVES) void k_lsd_grow4(LineParams P, 
     const int words = (int)((npx + 31) >> 5);
     LsdW F;
     F.W = P.W; F.H = P.H; F.lane = lane;
-    F.ang = angdeg + frame * npx; F.mod = modgrad + frame * npx; F.trig = trig + frame * npx; F.reg = reg + frame * npx;
+    F.ang = angdeg + frame * npx; F.mod = modgrad + frame * npx; F.trig = trig + frame * npx; F.used = used + frame * npx; F.reg = reg + frame * npx;
     F.seedt = seedt + frame * npx; F.ring = s_ring; F.term = s_term; F.sctab = P.sctab; F.map = s_map;
     F.interior = __ballot((lane & 7) >= 1 && (lane & 7) <= 6 && (lane >> 3) >= 1 && (lane >> 3) <= 6);
     const LsdgFast fcP = lsdg_fast_setup(P.prec);

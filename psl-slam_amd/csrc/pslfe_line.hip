@@ -29,8 +29,9 @@ struct pslfe_line {
     double* d_scaled = nullptr;
     float* d_angdeg = nullptr;
     double* d_modgrad = nullptr;
-    float4* d_trig = nullptr;
+    float2* d_trig = nullptr;     // (cosf, sinf) of the level-line angle per scaled pixel
     float2* d_seedt = nullptr;
+    uint8_t* d_used = nullptr;    // LSD `used` map, one byte per scaled pixel
     uint32_t* d_reg = nullptr;
     LsdnTables NT = {};           // LSD_REFINE_ADV: log_gamma / log(p) tables of nfa() (NT.lg in HBM)
     double* d_lgamma = nullptr;
@@ -70,6 +71,7 @@ struct pslfe_line {
         d_rawfans = nullptr; d_fans = nullptr; d_nfans = nullptr; d_tmplines = nullptr;
         hipFree(d_trig); d_trig = nullptr;
         hipFree(d_seedt); d_seedt = nullptr;
+        hipFree(d_used); d_used = nullptr;
         hipFree(d_in); hipFree(d_scaled); hipFree(d_angdeg); hipFree(d_modgrad); hipFree(d_reg);
         hipFree(d_seg); hipFree(d_nseg); hipFree(d_rects); hipFree(d_nrect); hipFree(d_segtmp); hipFree(d_keep); hipFree(d_lgamma); hipFree(d_sctab);
         d_sctab = nullptr; hipFree(d_counts); hipFree(d_vals); hipFree(d_sstate); hipFree(d_slist); hipFree(d_stmp); hipFree(d_lcount);
@@ -154,8 +156,9 @@ struct pslfe_line {
         PSL_ALLOC(d_scaled, npx * F * sizeof(double));
         PSL_ALLOC(d_angdeg, npx * F * sizeof(float));
         PSL_ALLOC(d_modgrad, npx * F * sizeof(double));
-        PSL_ALLOC(d_trig, npx * F * sizeof(float4));
+        PSL_ALLOC(d_trig, npx * F * sizeof(float2));
         PSL_ALLOC(d_seedt, npx * F * sizeof(float2));
+        PSL_ALLOC(d_used, npx * F);
         PSL_ALLOC(d_reg, npx * F * sizeof(uint32_t));
         PSL_ALLOC(d_seg, (size_t)Q.maxseg * 4 * sizeof(float) * F);
         PSL_ALLOC(d_nseg, F * sizeof(int));
@@ -244,6 +247,7 @@ struct pslfe_line {
         }
         {
             PSL_STAGE_BEGIN(ctx, "line.lsd_grad");
+            if (hipMemsetAsync(d_used, 0, (size_t)P.W * P.H * F, st) != hipSuccess) return PSLFE_E_HIP;  // the `used` map: 1 byte per scaled pixel
             P.full_grad = nframes == 1;  // pslfe_line_debug_gradient reads the whole magnitude image of a single-frame call
             k_lsd_grad<<<dim3((P.W + 63) / 64, (P.H + PSL_GRAD_TH - 1) / PSL_GRAD_TH, F), 256, 0, st>>>(P, d_scaled, d_angdeg, d_modgrad, d_trig, d_seedt);
             PSL_STAGE_END(ctx, "line.lsd_grad");
@@ -252,7 +256,7 @@ struct pslfe_line {
         {
             PSL_STAGE_BEGIN(ctx, "line.lsd_grow");
             // LSD_REFINE_ADV: the kernel leaves rectangles (d_rects / d_nrect) for the NFA validation below
-            k_lsd_grow4<<<F, 64, 0, st>>>(P, d_angdeg, d_modgrad, d_trig, d_seedt, d_reg, d_seg, refine >= 2 ? d_nrect : d_nseg, d_rects);
+            k_lsd_grow4<<<F, 64, 0, st>>>(P, d_angdeg, d_modgrad, d_trig, d_used, d_seedt, d_reg, d_seg, refine >= 2 ? d_nrect : d_nseg, d_rects);
             PSL_STAGE_END(ctx, "line.lsd_grow");
         }
         if (refine >= 2) {
