@@ -810,9 +810,10 @@ __device__ __forceinline__ void psl_lsd_store_segment(const LineParams& P, doubl
 // HELPERS: launches of a few frames (one workgroup per XCD at most) run the chain on wave 0 and let HELPERS more waves of the same
 // workgroup - hence the same XCD's L2 - read one dword of every 64-byte piece of the frame's neighbour records, angles and `used` map
 // (13 bytes per pixel: 2.6 MB of the 4 MB L2 at 640x480), top of the frame first: the chain's ~6 000 dependent round trips then
-// end in L2 instead of HBM (one frame: 12.9 -> 11.9 ms).  No effect on results.  Not used where it cannot pay: with thousands of
-// frames in flight there is no L2 to spare and no idle wave slot, and a 1280x960 frame (10 MB) does not fit - measured 25.2 ms against
-// 24.6 ms without; seed vectors and magnitudes prefetched at defined pixels as well: no further gain.
+// end in L2 instead of HBM (one frame: 12.9 -> 11.9 ms).  The helpers stay at most 2.5 MB in front of the seed scan, whose position
+// wave 0 publishes in LDS, so that a larger frame (1280x960: 10 MB) keeps a band in front of the scan warm instead of flushing the
+// cache (all of it at once: 25.2 ms against 24.6 ms without helpers).  No effect on results.  Not used with thousands of frames in
+// flight: no L2 to spare and no idle wave slot.  Seed vectors and magnitudes prefetched at defined pixels as well: no further gain.
 template <int HELPERS>
 __global__ __launch_bounds__(64 * (1 + HELPERS), HELPERS ? 1 : PSL_GROW_WAVES) void k_lsd_grow4(LineParams P, const float* __restrict__ angdeg, const double* __restrict__ modgrad,
                                                    const float2* __restrict__ trig, uint8_t* __restrict__ used, const float2* __restrict__ seedt, uint32_t* __restrict__ reg,
@@ -827,19 +828,30 @@ __global__ __launch_bounds__(64 * (1 + HELPERS), HELPERS ? 1 : PSL_GROW_WAVES) v
     F.W = P.W; F.H = P.H; F.lane = lane;
     F.ang = angdeg + frame * npx; F.mod = modgrad + frame * npx; F.trig = trig + frame * npx; F.used = used + frame * npx; F.reg = reg + frame * npx;
     F.seedt = seedt + frame * npx; F.ring = s_ring; F.term = s_term; F.sctab = P.sctab; F.map = s_map;
+    __shared__ int s_scan_unit;  // HELPERS: the 64-pixel unit the seed scan has reached (written by wave 0, polled by the helpers)
+    if (HELPERS) {
+        if (threadIdx.x == 0) s_scan_unit = 0;
+        __syncthreads();
+    }
     if (HELPERS && threadIdx.x >= 64) {
         const char* pt = (const char*)F.trig;
         const char* pa = (const char*)F.ang;
         const char* pu = (const char*)F.used;
         const int units = (int)(npx >> 6);  // 64 pixels: 8 pieces of records, 4 of angles, 1 of the map
+        const int ahead = (int)(((size_t)5 << 19) / (64 * 13));  // stay at most 2.5 MB (of the 4 MB L2) in front of the scan
         // The loads are never waited for individually, so their destination must stay reserved until the final wait: ONE register,
         // read-write operand of every load and consumed after the wait (an output-only operand is free for reuse - as the next
         // address, say - while the load is still in flight).
         uint32_t sink = 0;
-        for (int j = (int)threadIdx.x - 64; j < units * 13; j += 64 * HELPERS) {
-            const int u = j / 13, k = j - u * 13;
-            const char* q = k < 8 ? pt + (size_t)u * 512 + k * 64 : (k < 12 ? pa + (size_t)u * 256 + (k - 8) * 64 : pu + (size_t)u * 64);
-            asm volatile("global_load_dword %0, %1, off" : "+v"(sink) : "v"(q) : "memory");
+        int j = (int)threadIdx.x - 64;
+        while (j < units * 13) {
+            const int lim = min(units, *(volatile int*)&s_scan_unit + ahead) * 13;
+            if (j >= lim) { __builtin_amdgcn_s_sleep(64); continue; }  // the scan's last update is `units`: every helper gets to the end
+            for (; j < lim; j += 64 * HELPERS) {
+                const int u = j / 13, k = j - u * 13;
+                const char* q = k < 8 ? pt + (size_t)u * 512 + k * 64 : (k < 12 ? pa + (size_t)u * 256 + (k - 8) * 64 : pu + (size_t)u * 64);
+                asm volatile("global_load_dword %0, %1, off" : "+v"(sink) : "v"(q) : "memory");
+            }
         }
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(sink) : : "memory");
         return;
@@ -864,6 +876,7 @@ __global__ __launch_bounds__(64 * (1 + HELPERS), HELPERS ? 1 : PSL_GROW_WAVES) v
         // dominated by the inlined region growing, and four copies of it did not fit the instruction cache.
         unsigned long long dm[4], um[4];
         const int trip_end = min(base + 256, scan_end);
+        if (HELPERS && lane == 0) *(volatile int*)&s_scan_unit = base >> 6;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // marks of the last region's last round
         {
             float a4[4];
@@ -931,6 +944,7 @@ __global__ __launch_bounds__(64 * (1 + HELPERS), HELPERS ? 1 : PSL_GROW_WAVES) v
             }
         }
     }
+    if (HELPERS && lane == 0) *(volatile int*)&s_scan_unit = (int)(npx >> 6);  // the helpers' exit condition
     if (lane == 0) nseg[frame] = count < P.maxseg ? count : P.maxseg;
 #ifdef PSL_GROW_STATS
     if (frame == 0 && lane == 0) {

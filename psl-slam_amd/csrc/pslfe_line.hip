@@ -256,13 +256,10 @@ struct pslfe_line {
         {
             PSL_STAGE_BEGIN(ctx, "line.lsd_grow");
             // LSD_REFINE_ADV: the kernel leaves rectangles (d_rects / d_nrect) for the NFA validation below
-            if (F <= 8 && (size_t)P.W * P.H * 13 <= (3u << 20)) {
-                // one workgroup per XCD at most and a frame whose neighbour records, angles and `used` map fit that XCD's L2: three more waves
-                // warm it for the chain (line_kernels.h)
+            if (F <= 8)  // one workgroup per XCD at most: three more waves keep that XCD's L2 warm in front of the chain (line_kernels.h)
                 k_lsd_grow4<3><<<F, 256, 0, st>>>(P, d_angdeg, d_modgrad, d_trig, d_used, d_seedt, d_reg, d_seg, refine >= 2 ? d_nrect : d_nseg, d_rects);
-            } else {
+            else
                 k_lsd_grow4<0><<<F, 64, 0, st>>>(P, d_angdeg, d_modgrad, d_trig, d_used, d_seedt, d_reg, d_seg, refine >= 2 ? d_nrect : d_nseg, d_rects);
-            }
             PSL_STAGE_END(ctx, "line.lsd_grow");
         }
         if (refine >= 2) {
