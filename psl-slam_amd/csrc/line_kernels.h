@@ -227,15 +227,27 @@ __device__ __forceinline__ bool psl_lsd_norm(const LineParams& P, const double* 
 // only for those - about a third of the pixels (16-byte records for every pixel made this kernel HBM-write-bound, 9.4 - 11.5 ms).
 // Which pixels have a defined neighbour is known from a flag tile in LDS: 64 x 16 pixels per workgroup plus a one-pixel ring whose
 // magnitudes are recomputed.  8-byte records: a window row of the growing is 64 bytes, 1 - 2 HBM sectors instead of 2 - 3.
+// The heavy part of a defined pixel (f64 square root, fastAtan2, two sine / cosine pairs: ~160 vector instructions) runs on the
+// COMPACTED list of the tile's defined pixels: ~15 % of the pixels have a defined angle and they are scattered, so that run in place
+// nearly every wave executed it for each of its four pixel slots with a handful of lanes active (7.7 ms per 6144 frames).  Phase A
+// (thread = 4 pixels of a column): gradient and squared magnitude, the threshold, NOTDEF angles, the flag tile, and the defined
+// pixels appended to an LDS list (any order: every output is a per-pixel store).  Phase B (thread = list entry): magnitude, angle,
+// records.  Phase C: the neighbour records of the pixels that have a defined pixel in their 3 x 3.
 __global__ __launch_bounds__(256) void k_lsd_grad(LineParams P, const double* __restrict__ scaled, float* __restrict__ angdeg,
-                                                   double* __restrict__ modgrad, float2* __restrict__ trig, float2* __restrict__ seedt) {
+                                                   double* __restrict__ modgrad, float2* __restrict__ trig, float2* __restrict__ seedt, int nframes, int xcd) {
     __shared__ uint8_t s_def[PSL_GRAD_TH + 2][68];
-    const int frame = blockIdx.z, tid = threadIdx.x;
-    const int x0 = blockIdx.x * 64, y0 = blockIdx.y * PSL_GRAD_TH;
+    __shared__ float2 s_cs[PSL_GRAD_TH * 64];    // (cosf, sinf) of the tile's pixels, (0, 0) = undefined
+    __shared__ uint16_t s_px[PSL_GRAD_TH * 64];  // list: pixel of the tile (row * 64 + column); its gradient is formed again from the
+                                                 // four values (L1 hits): keeping it in LDS cost a third of the resident workgroups
+    __shared__ int s_n;
+    int tile_x, tile_y, frame;  // XCD-aware grid for many frames: the tiles of a frame share one L2 (their halos overlap)
+    if (!psl_tile_frame((P.W + 63) / 64, nframes, xcd, &tile_x, &tile_y, &frame)) return;
+    const int tid = threadIdx.x;
+    const int x0 = tile_x * 64, y0 = tile_y * PSL_GRAD_TH;
     const int tx = tid & 63, ty = tid >> 6, x = x0 + tx;
     const size_t fo = (size_t)frame * P.W * P.H;
     const double* img = scaled + fo;
-    float cs[4], sn[4], dg[4];
+    if (tid == 0) s_n = 0;
     // all sixteen loads of the thread's four pixels first (clamped addresses), then the arithmetic: one memory round trip
     double w00[4], w01[4], w10[4], w11[4];
 #pragma unroll
@@ -244,16 +256,15 @@ __global__ __launch_bounds__(256) void k_lsd_grad(LineParams P, const double* __
         const double* r0 = img + (size_t)yy * P.W + xx;
         w00[i] = r0[0]; w01[i] = r0[1]; w10[i] = r0[P.W]; w11[i] = r0[P.W + 1];
     }
+    __syncthreads();
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int r = ty + 4 * i, y = y0 + r;
         bool def = false;
-        dg[i] = PSL_LSD_NOTDEF; cs[i] = 0.f; sn[i] = 0.f;
+        double gx = 0.0, gy = 0.0, q = 0.0;
         if (x < P.W && y < P.H) {
             const size_t o = fo + (size_t)y * P.W + x;
-            double norm = 0.0, gx = 0.0, gy = 0.0;
             const bool inner = x < P.W - 1 && y < P.H - 1;  // last column / row: magnitude 0, angle undefined by construction
-            double q = 0.0;
             if (inner) {
                 const double DA = PSL_DSUB(w11[i], w00[i]), BC = PSL_DSUB(w01[i], w10[i]);
                 gx = PSL_DADD(DA, BC); gy = PSL_DSUB(DA, BC);
@@ -263,19 +274,23 @@ __global__ __launch_bounds__(256) void k_lsd_grad(LineParams P, const double* __
             // pixels below the threshold need no square root.  The magnitude is read back only for pixels of regions (defined
             // angle): many-frames launches skip the other stores.
             def = inner && !(q <= P.rho_q);
-            if (def || P.full_grad) { norm = __dsqrt_rn(q); modgrad[o] = norm; }
-            if (def) {
-                const float deg = psl_fast_atan2((float)gx, (float)(-gy));
-                const double ad = PSL_DMUL((double)deg, PSL_DEG2RAD);
-                psl_sincosf((float)ad, &sn[i], &cs[i]);
-                float cd, sd;  // (float)cos(ad), (float)sin(ad): restricted-range evaluation, pinned exhaustively (psl_sincos64.h)
-                psl_cos_sin_2pi_f32(ad, &cd, &sd);
-                seedt[o] = make_float2(cd, sd);
-                dg[i] = deg;
+            if (!def) {
+                if (P.full_grad) modgrad[o] = __dsqrt_rn(q);
+                angdeg[o] = PSL_LSD_NOTDEF;
             }
-            angdeg[o] = dg[i];
+        }
+        const unsigned long long dmask = __ballot(def);
+        if (dmask) {  // one LDS atomic per wave, positions by rank
+            int base = 0;
+            if (tx == 0) base = atomicAdd(&s_n, __popcll(dmask));
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (def) {
+                const int k = base + __popcll(dmask & ((1ull << tx) - 1ull));
+                s_px[k] = (uint16_t)(r * 64 + tx);
+            }
         }
         s_def[r + 1][tx + 1] = def;
+        s_cs[r * 64 + tx] = make_float2(0.f, 0.f);
     }
     // the ring around the tile: 2 x 66 + 2 x 16 = 164 pixels
     if (tid < 2 * 66 + 2 * PSL_GRAD_TH) {
@@ -287,6 +302,25 @@ __global__ __launch_bounds__(256) void k_lsd_grad(LineParams P, const double* __
         s_def[r][c] = inner && !(q <= P.rho_q);
     }
     __syncthreads();
+    const int n = s_n;
+    for (int k = tid; k < n; k += 256) {
+        const int px = s_px[k], r = px >> 6, c = px & 63;
+        const size_t o = fo + (size_t)(y0 + r) * P.W + (x0 + c);
+        const double* r0 = img + (size_t)(y0 + r) * P.W + (x0 + c);
+        const double DA = PSL_DSUB(r0[P.W + 1], r0[0]), BC = PSL_DSUB(r0[1], r0[P.W]);
+        const double gx = PSL_DADD(DA, BC), gy = PSL_DSUB(DA, BC);
+        modgrad[o] = __dsqrt_rn(PSL_DADD(PSL_DMUL(gx, gx), PSL_DMUL(gy, gy)) / 4);
+        const float deg = psl_fast_atan2((float)gx, (float)(-gy));
+        const double ad = PSL_DMUL((double)deg, PSL_DEG2RAD);
+        float sn, cs;
+        psl_sincosf((float)ad, &sn, &cs);
+        float cd, sd;  // (float)cos(ad), (float)sin(ad): restricted-range evaluation, pinned exhaustively (psl_sincos64.h)
+        psl_cos_sin_2pi_f32(ad, &cd, &sd);
+        seedt[o] = make_float2(cd, sd);
+        angdeg[o] = deg;
+        s_cs[px] = make_float2(cs, sn);
+    }
+    __syncthreads();
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int r = ty + 4 * i, y = y0 + r;
@@ -295,7 +329,7 @@ __global__ __launch_bounds__(256) void k_lsd_grad(LineParams P, const double* __
         const uint8_t* d1 = &s_def[r + 1][tx];
         const uint8_t* d2 = &s_def[r + 2][tx];
         const bool any = (d0[0] | d0[1] | d0[2] | d1[0] | d1[1] | d1[2] | d2[0] | d2[1] | d2[2]) != 0;
-        if (any) trig[fo + (size_t)y * P.W + x] = make_float2(cs[i], sn[i]);
+        if (any) trig[fo + (size_t)y * P.W + x] = s_cs[r * 64 + tx];
     }
 }
 
