@@ -851,7 +851,7 @@ __device__ __forceinline__ void psl_lsd_store_segment(const LineParams& P, doubl
 template <int HELPERS>
 __global__ __launch_bounds__(64 * (1 + HELPERS), HELPERS ? 1 : PSL_GROW_WAVES) void k_lsd_grow4(LineParams P, const float* __restrict__ angdeg, const double* __restrict__ modgrad,
                                                    const float2* __restrict__ trig, uint8_t* __restrict__ used, const float2* __restrict__ seedt, uint32_t* __restrict__ reg,
-                                                   float* __restrict__ seg, int* __restrict__ nseg, double* __restrict__ rects) {
+                                                   float* __restrict__ seg, int* __restrict__ nseg, double* __restrict__ rects, int nframes) {
     __shared__ uint32_t s_ring[PSL_LSD_RING];
     __shared__ double s_term[3 * 64];
     __shared__ uint32_t s_map[64];
@@ -872,7 +872,7 @@ __global__ __launch_bounds__(64 * (1 + HELPERS), HELPERS ? 1 : PSL_GROW_WAVES) v
         const char* pa = (const char*)F.ang;
         const char* pu = (const char*)F.used;
         const int units = (int)(npx >> 6);  // 64 pixels: 8 pieces of records, 4 of angles, 1 of the map
-        const int ahead = (int)(((size_t)5 << 19) / (64 * 13));  // stay at most 2.5 MB (of the 4 MB L2) in front of the scan
+        const int ahead = (int)(((size_t)5 << 19) / (64 * 13)) / ((nframes + 7) / 8);  // all helpers of an XCD together stay at most 2.5 MB (of its 4 MB L2) in front of their scans
         // The loads are never waited for individually, so their destination must stay reserved until the final wait: ONE register,
         // read-write operand of every load and consumed after the wait (an output-only operand is free for reuse - as the next
         // address, say - while the load is still in flight).

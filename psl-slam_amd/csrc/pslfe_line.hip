@@ -11,6 +11,9 @@
 #include "line_kernels3.h"
 #include "pslfe_internal.h"
 
+#ifndef PSL_GROW_HELPER_FRAMES
+#define PSL_GROW_HELPER_FRAMES 64   // launches of at most this many frames run k_lsd_grow4 with helper waves (measured: tools/helper_sweep.sh)
+#endif
 struct pslfe_line {
     pslfe_ctx* ctx = nullptr;
     int numOctaves = 1, nfeatures = 200, max_batch = 1;
@@ -258,10 +261,10 @@ struct pslfe_line {
         {
             PSL_STAGE_BEGIN(ctx, "line.lsd_grow");
             // LSD_REFINE_ADV: the kernel leaves rectangles (d_rects / d_nrect) for the NFA validation below
-            if (F <= 8)  // one workgroup per XCD at most: three more waves keep that XCD's L2 warm in front of the chain (line_kernels.h)
-                k_lsd_grow4<3><<<F, 256, 0, st>>>(P, d_angdeg, d_modgrad, d_trig, d_used, d_seedt, d_reg, d_seg, refine >= 2 ? d_nrect : d_nseg, d_rects);
+            if (F <= PSL_GROW_HELPER_FRAMES)  // few workgroups per XCD: three more waves each keep that XCD's L2 warm in front of the chain (line_kernels.h)
+                k_lsd_grow4<3><<<F, 256, 0, st>>>(P, d_angdeg, d_modgrad, d_trig, d_used, d_seedt, d_reg, d_seg, refine >= 2 ? d_nrect : d_nseg, d_rects, (int)F);
             else
-                k_lsd_grow4<0><<<F, 64, 0, st>>>(P, d_angdeg, d_modgrad, d_trig, d_used, d_seedt, d_reg, d_seg, refine >= 2 ? d_nrect : d_nseg, d_rects);
+                k_lsd_grow4<0><<<F, 64, 0, st>>>(P, d_angdeg, d_modgrad, d_trig, d_used, d_seedt, d_reg, d_seg, refine >= 2 ? d_nrect : d_nseg, d_rects, (int)F);
             PSL_STAGE_END(ctx, "line.lsd_grow");
         }
         if (refine >= 2) {
