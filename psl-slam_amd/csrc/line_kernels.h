@@ -237,6 +237,7 @@ __global__ __launch_bounds__(256) void k_lsd_grad(LineParams P, const double* __
                                                    double* __restrict__ modgrad, float2* __restrict__ trig, float2* __restrict__ seedt, int nframes, int xcd) {
     __shared__ uint8_t s_def[PSL_GRAD_TH + 2][68];
     __shared__ float2 s_cs[PSL_GRAD_TH * 64];    // (cosf, sinf) of the tile's pixels, (0, 0) = undefined
+    __shared__ float s_deg[PSL_GRAD_TH * 64];    // their angles: written to HBM as whole rows in phase C
     __shared__ uint16_t s_px[PSL_GRAD_TH * 64];  // list: pixel of the tile (row * 64 + column); its gradient is formed again from the
                                                  // four values (L1 hits): keeping it in LDS cost a third of the resident workgroups
     __shared__ int s_n;
@@ -274,10 +275,7 @@ __global__ __launch_bounds__(256) void k_lsd_grad(LineParams P, const double* __
             // pixels below the threshold need no square root.  The magnitude is read back only for pixels of regions (defined
             // angle): many-frames launches skip the other stores.
             def = inner && !(q <= P.rho_q);
-            if (!def) {
-                if (P.full_grad) modgrad[o] = __dsqrt_rn(q);
-                angdeg[o] = PSL_LSD_NOTDEF;
-            }
+            if (!def && P.full_grad) modgrad[o] = __dsqrt_rn(q);
         }
         const unsigned long long dmask = __ballot(def);
         if (dmask) {  // one LDS atomic per wave, positions by rank
@@ -291,6 +289,7 @@ __global__ __launch_bounds__(256) void k_lsd_grad(LineParams P, const double* __
         }
         s_def[r + 1][tx + 1] = def;
         s_cs[r * 64 + tx] = make_float2(0.f, 0.f);
+        s_deg[r * 64 + tx] = PSL_LSD_NOTDEF;
     }
     // the ring around the tile: 2 x 66 + 2 x 16 = 164 pixels
     if (tid < 2 * 66 + 2 * PSL_GRAD_TH) {
@@ -317,7 +316,7 @@ __global__ __launch_bounds__(256) void k_lsd_grad(LineParams P, const double* __
         float cd, sd;  // (float)cos(ad), (float)sin(ad): restricted-range evaluation, pinned exhaustively (psl_sincos64.h)
         psl_cos_sin_2pi_f32(ad, &cd, &sd);
         seedt[o] = make_float2(cd, sd);
-        angdeg[o] = deg;
+        s_deg[px] = deg;
         s_cs[px] = make_float2(cs, sn);
     }
     __syncthreads();
@@ -329,6 +328,7 @@ __global__ __launch_bounds__(256) void k_lsd_grad(LineParams P, const double* __
         const uint8_t* d1 = &s_def[r + 1][tx];
         const uint8_t* d2 = &s_def[r + 2][tx];
         const bool any = (d0[0] | d0[1] | d0[2] | d1[0] | d1[1] | d1[2] | d2[0] | d2[1] | d2[2]) != 0;
+        angdeg[fo + (size_t)y * P.W + x] = s_deg[r * 64 + tx];
         if (any) trig[fo + (size_t)y * P.W + x] = s_cs[r * 64 + tx];
     }
 }
