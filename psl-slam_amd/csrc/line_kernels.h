@@ -42,6 +42,7 @@ struct LineParams {
     int refine;               // 1 = LSD_REFINE_STD (segments leave k_lsd_grow4), 2 = LSD_REFINE_ADV (rectangles -> k_lsd_nfa -> k_lsd_emit)
     double log_nt;            // LOG_NT of the NFA: 5 (log10 W + log10 H) / 2 + log10 11
     int full_grad;            // k_lsd_grad stores the gradient magnitude of every pixel (debug tap), not only where the angle is defined
+    int singles;              // k_lsd_grad flags static singletons in the `used` map (few-frame launches: it pays in the chain's latency, not in throughput)
     int lbdK[5];              // integer Gaussian 5x5 sigma 1 (OpenCV 3.2 8-bit path)
     float gaussG[63], gaussL[21];
 };
@@ -209,6 +210,9 @@ __global__ __launch_bounds__(256) void k_lsd_scale_tiled(LineParams P, const uin
 // Also tabulates, per pixel with a defined angle a = (double)deg * DEG_TO_RADS, the four values the
 // region-growing chain needs: cosf((float)a), sinf((float)a) (every pixel that joins a region) and
 // (float)cos(a), (float)sin(a) (the seed pixel), so that the serial chain contains no trigonometry.
+#ifndef PSL_LSD_SINGLES
+#define PSL_LSD_SINGLES 1   // 0: no static-singleton flags (A/B, tools/ab_build.sh)
+#endif
 #define PSL_GRAD_TH 16  // tile height of k_lsd_grad (64 x 16 pixels per workgroup, 4 per thread)
 // squared gradient magnitude of pixel (x, y); false where the reference leaves the angle undefined by construction
 __device__ __forceinline__ bool psl_lsd_norm(const LineParams& P, const double* __restrict__ img, int x, int y, double* q) {
@@ -227,6 +231,15 @@ __device__ __forceinline__ bool psl_lsd_norm(const LineParams& P, const double* 
 // only for those - about a third of the pixels (16-byte records for every pixel made this kernel HBM-write-bound, 9.4 - 11.5 ms).
 // Which pixels have a defined neighbour is known from a flag tile in LDS: 64 x 16 pixels per workgroup plus a one-pixel ring whose
 // magnitudes are recomputed.  8-byte records: a window row of the growing is 64 bytes, 1 - 2 HBM sectors instead of 2 - 3.
+// |theta - ad| folded into [0, pi] and compared with prec, as lsdw_aligned but without branches: both differences are formed
+// and one is selected (the serial acceptance chain below executes this once per accepted pixel).
+__device__ __forceinline__ double lsdg_fold(double ad, double theta) {
+    const double d = __builtin_fabs(PSL_DSUB(theta, ad));
+    const double d2 = __builtin_fabs(PSL_DSUB(d, 2 * PSL_PI));
+    return d > (3 * PSL_PI) / 2 ? d2 : d;
+}
+__device__ __forceinline__ bool lsdg_aligned(double ad, double theta, double prec) { return lsdg_fold(ad, theta) <= prec; }
+
 // The heavy part of a defined pixel (f64 square root, fastAtan2, two sine / cosine pairs: ~160 vector instructions) runs on the
 // COMPACTED list of the tile's defined pixels: ~15 % of the pixels have a defined angle and they are scattered, so that run in place
 // nearly every wave executed it for each of its four pixel slots with a handful of lanes active (7.7 ms per 6144 frames).  Phase A
@@ -234,10 +247,11 @@ __device__ __forceinline__ bool psl_lsd_norm(const LineParams& P, const double* 
 // pixels appended to an LDS list (any order: every output is a per-pixel store).  Phase B (thread = list entry): magnitude, angle,
 // records.  Phase C: the neighbour records of the pixels that have a defined pixel in their 3 x 3.
 __global__ __launch_bounds__(256) void k_lsd_grad(LineParams P, const double* __restrict__ scaled, float* __restrict__ angdeg,
-                                                   double* __restrict__ modgrad, float2* __restrict__ trig, float2* __restrict__ seedt, int nframes, int xcd) {
+                                                   double* __restrict__ modgrad, float2* __restrict__ trig, float2* __restrict__ seedt, uint8_t* __restrict__ used, int nframes, int xcd) {
     __shared__ uint8_t s_def[PSL_GRAD_TH + 2][68];
     __shared__ float2 s_cs[PSL_GRAD_TH * 64];    // (cosf, sinf) of the tile's pixels, (0, 0) = undefined
     __shared__ float s_deg[PSL_GRAD_TH * 64];    // their angles: written to HBM as whole rows in phase C
+    __shared__ uint8_t s_single[PSL_GRAD_TH * 64];  // 1: no neighbour's angle is aligned with this pixel's (phase B2)
     __shared__ uint16_t s_px[PSL_GRAD_TH * 64];  // list: pixel of the tile (row * 64 + column); its gradient is formed again from the
                                                  // four values (L1 hits): keeping it in LDS cost a third of the resident workgroups
     __shared__ int s_n;
@@ -290,6 +304,7 @@ __global__ __launch_bounds__(256) void k_lsd_grad(LineParams P, const double* __
         s_def[r + 1][tx + 1] = def;
         s_cs[r * 64 + tx] = make_float2(0.f, 0.f);
         s_deg[r * 64 + tx] = PSL_LSD_NOTDEF;
+        s_single[r * 64 + tx] = 0;
     }
     // the ring around the tile: 2 x 66 + 2 x 16 = 164 pixels
     if (tid < 2 * 66 + 2 * PSL_GRAD_TH) {
@@ -320,10 +335,33 @@ __global__ __launch_bounds__(256) void k_lsd_grad(LineParams P, const double* __
         s_cs[px] = make_float2(cs, sn);
     }
     __syncthreads();
+    // Phase B2, STATIC SINGLETONS: a pixel none of whose eight neighbours has an angle aligned with ITS angle (the reference's
+    // isAligned with the detector's tolerance) grows, as a seed, into a region of exactly one pixel whatever has been used by then -
+    // a region the size test drops.  Such a seed is marked in the `used` map (value 2) and k_lsd_grow4's scan only takes it (used = 1)
+    // instead of growing it: 40 % of the region starts of the headline scene.  Measured A/B in one session: one frame at a time -1 %
+    // (structure scene) to -7 % (textured scene, 35.0 -> 32.6 ms); launches of thousands of frames gain nothing (the launch lasts as
+    // long as its heaviest frames) and pay 0.3 ms here: P.singles is set for launches of at most 64 frames.  (It can still be absorbed by a neighbour's region
+    // before the scan reaches it: the test there is against the REGION's angle.)  Only pixels whose neighbours all lie in the tile
+    // are examined; the others go the ordinary way.
+    for (int k = tid; PSL_LSD_SINGLES && P.singles && k < n; k += 256) {
+        const int px = s_px[k], r = px >> 6, c = px & 63;
+        if (r < 1 || r > PSL_GRAD_TH - 2 || c < 1 || c > 62) continue;
+        const double ap = PSL_DMUL((double)s_deg[px], PSL_DEG2RAD);
+        bool alone = true;
+#pragma unroll
+        for (int j = 0; j < 9; ++j) {
+            if (j == 4) continue;
+            const float an = s_deg[px + (j / 3 - 1) * 64 + (j % 3 - 1)];
+            if (an != PSL_LSD_NOTDEF && lsdg_aligned(PSL_DMUL((double)an, PSL_DEG2RAD), ap, P.prec)) alone = false;
+        }
+        if (alone) s_single[px] = 1;
+    }
+    __syncthreads();
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int r = ty + 4 * i, y = y0 + r;
         if (x >= P.W || y >= P.H) continue;
+        if (s_single[r * 64 + tx]) used[fo + (size_t)y * P.W + x] = 2;
         const uint8_t* d0 = &s_def[r][tx];
         const uint8_t* d1 = &s_def[r + 1][tx];
         const uint8_t* d2 = &s_def[r + 2][tx];
@@ -397,21 +435,15 @@ __device__ __forceinline__ uint32_t lsdw_reg(const LsdW& F, int idx, int reg_siz
     return (reg_size - idx <= PSL_LSD_RING) ? F.ring[idx & (PSL_LSD_RING - 1)] : F.reg[idx];
 }
 
-__device__ __forceinline__ bool lsdg_used(const LsdW& F, int a) {
-    return __hip_atomic_load(F.used + a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0;
+// the `used` map: 0 free, 1 used, 2 free and a static singleton (k_lsd_grad, phase B2)
+__device__ __forceinline__ uint32_t lsdg_state(const LsdW& F, int a) {
+    return __hip_atomic_load(F.used + a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
+__device__ __forceinline__ bool lsdg_used(const LsdW& F, int a) { return lsdg_state(F, a) == 1u; }
 __device__ __forceinline__ void lsdg_mark(const LsdW& F, int a, uint8_t v) {
     __hip_atomic_store(F.used + a, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-// |theta - ad| folded into [0, pi] and compared with prec, as lsdw_aligned but without branches: both differences are formed
-// and one is selected (the serial acceptance chain below executes this once per accepted pixel).
-__device__ __forceinline__ double lsdg_fold(double ad, double theta) {
-    const double d = __builtin_fabs(PSL_DSUB(theta, ad));
-    const double d2 = __builtin_fabs(PSL_DSUB(d, 2 * PSL_PI));
-    return d > (3 * PSL_PI) / 2 ? d2 : d;
-}
-__device__ __forceinline__ bool lsdg_aligned(double ad, double theta, double prec) { return lsdg_fold(ad, theta) <= prec; }
 // ---------------------------------------------------------------------------------------------
 // Region growing in WINDOW ROUNDS.  The queue order of the reference (breadth first, 3 x 3 neighbours in raster order, the
 // region angle brought up to date after every pixel) is kept exactly; what changes is how much of it one memory round trip serves.
@@ -908,7 +940,7 @@ __global__ __launch_bounds__(64 * (1 + HELPERS), HELPERS ? 1 : PSL_GROW_WAVES) v
         // four 64-pixel rows per trip, their loads in flight together; what is kept of them is wave-uniform: the masks of
         // pixels with a defined angle and of used pixels.  The seed loop below exists ONCE (not per row): the kernel's code is
         // dominated by the inlined region growing, and four copies of it did not fit the instruction cache.
-        unsigned long long dm[4], um[4];
+        unsigned long long dm[4], um[4], sm[4];
         const int trip_end = min(base + 256, scan_end);
         if (HELPERS && lane == 0) *(volatile int*)&s_scan_unit = base >> 6;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // marks of the last region's last round
@@ -919,12 +951,13 @@ __global__ __launch_bounds__(64 * (1 + HELPERS), HELPERS ? 1 : PSL_GROW_WAVES) v
             for (int q = 0; q < 4; ++q) {
                 const int ad = base + q * 64 + lane;
                 a4[q] = ad < scan_end ? F.ang[ad] : PSL_LSD_NOTDEF;
-                u4[q] = ad < scan_end ? (uint32_t)lsdg_used(F, ad) : 1u;
+                u4[q] = ad < scan_end ? lsdg_state(F, ad) : 1u;
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 dm[q] = __ballot(a4[q] != PSL_LSD_NOTDEF);  // column W-1 and row H-1 are NOTDEF by construction
-                um[q] = __ballot(u4[q] != 0);
+                um[q] = __ballot(u4[q] == 1u);
+                sm[q] = P.min_reg_size > 1 ? __ballot(u4[q] == 2u) : 0ull;  // static singletons (their flag never changes; taken ones drop out through um)
             }
         }
         // The bitmap changes only through the regions grown here: after each processed seed the remaining candidates
@@ -936,6 +969,7 @@ __global__ __launch_bounds__(64 * (1 + HELPERS), HELPERS ? 1 : PSL_GROW_WAVES) v
         for (int q = 0; q < 4; ++q) {
             const unsigned long long dmq = q == 0 ? dm[0] : q == 1 ? dm[1] : q == 2 ? dm[2] : dm[3];
             unsigned long long umq = q == 0 ? um[0] : q == 1 ? um[1] : q == 2 ? um[2] : um[3];
+            const unsigned long long smq = q == 0 ? sm[0] : q == 1 ? sm[1] : q == 2 ? sm[2] : sm[3];
             if (!dmq) continue;
             const int ad = base + q * 64 + lane;
             if (stale) {
@@ -956,6 +990,19 @@ __global__ __launch_bounds__(64 * (1 + HELPERS), HELPERS ? 1 : PSL_GROW_WAVES) v
                 mask &= mask - 1;
                 int x = trip_x + q * 64 + s, y = trip_y;
                 while (x >= P.W) { x -= P.W; ++y; }
+                if ((smq >> s) & 1ull) {
+                    // a static singleton: the region it would grow is itself.  Its mark joins the pending ones if it lies in their window;
+                    // otherwise those are waited for and it opens a window of its own.
+                    const int dxp = x - pd.pox, dyp = y - pd.poy;
+                    if (pd.PA != 0ull && (unsigned)dxp < 8u && (unsigned)dyp < 8u) {
+                        pd.PA |= 1ull << (dyp * 8 + dxp);
+                    } else {
+                        if (pd.PA != 0ull) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        pd.PA = 1ull; pd.pox = x; pd.poy = y;
+                    }
+                    if (lane == 0) lsdg_mark(F, x + y * P.W, 1);
+                    continue;
+                }
                 double reg_angle;
                 bool touched = false;
                 int reg_size = lsdg_region_grow4(F, x, y, &reg_angle, P.prec, fcP, pd, false, trip_end, touched);

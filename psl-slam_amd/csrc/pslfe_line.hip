@@ -251,10 +251,11 @@ struct pslfe_line {
         {
             PSL_STAGE_BEGIN(ctx, "line.lsd_grad");
             if (hipMemsetAsync(d_used, 0, (size_t)P.W * P.H * F, st) != hipSuccess) return PSLFE_E_HIP;  // the `used` map: 1 byte per scaled pixel
+            P.singles = F <= PSL_GROW_HELPER_FRAMES;
             P.full_grad = nframes == 1;  // pslfe_line_debug_gradient reads the whole magnitude image of a single-frame call
             const unsigned gx = (P.W + 63) / 64, gy = (P.H + PSL_GRAD_TH - 1) / PSL_GRAD_TH;
             const int gxcd = F >= 8 ? 1 : 0;
-            k_lsd_grad<<<gxcd ? dim3(8, gx * gy, (F + 7) / 8) : dim3(gx, gy, F), 256, 0, st>>>(P, d_scaled, d_angdeg, d_modgrad, d_trig, d_seedt, (int)F, gxcd);
+            k_lsd_grad<<<gxcd ? dim3(8, gx * gy, (F + 7) / 8) : dim3(gx, gy, F), 256, 0, st>>>(P, d_scaled, d_angdeg, d_modgrad, d_trig, d_seedt, d_used, (int)F, gxcd);
             PSL_STAGE_END(ctx, "line.lsd_grad");
         }
         P.refine = refine;
