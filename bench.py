@@ -3,7 +3,7 @@
 
 Workloads (BASELINE.json configs):
   lines     (default) configs[2], the configuration the headline metric "frames/sec ORB+line extract+match, 640x480 RGB-D" is
-            quoted on: a step = one pass over a batch of B = 6144 frames already resident in HBM - ORB extraction (pyramid,
+            quoted on: a step = one pass over a batch of B = 12288 frames already resident in HBM - ORB extraction (pyramid,
             per-cell FAST, octree, orientation, blur, rBRIEF) + frame grid + ORBmatcher::SearchByProjection(cur,last) against
             the predecessor frame, and the line path (LSD with LSD_REFINE_ADV, merge, top-200, LBD, LIL pairing, the RGB-D
             line glue of the Frame constructor, LSDmatcher::match).  The batch holds 256 DISTINCT frames (8 scenes x 32 time
@@ -238,7 +238,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=0, help="timed steps (default 20; 100 frames for dropin / 40 for tracking)")
     ap.add_argument("--warmup", type=int, default=-1, help="untimed warm-up steps (default 3; 10 frames for dropin / tracking)")
-    ap.add_argument("--batch", type=int, default=0, help="frames per step per GPU (default 6144 = 6 LSD waves per SIMD; 256 for --workload orb)")
+    ap.add_argument("--batch", type=int, default=0, help="frames per step per GPU (default 12288 = two rounds of the 6144 wave slots of the LSD growing, ~225 GB of HBM; 256 for --workload orb)")
     ap.add_argument("--workload", choices=["orb", "lines", "dropin", "tracking"], default="lines",
                     help="lines = BASELINE configs[2], the configuration of the headline metric; orb = configs[1]; dropin = B = 1 through the "
                          "C++ consumer; tracking = configs[4] through the C++ consumer")
@@ -264,7 +264,7 @@ def main():
         return run_consumer(args)
 
     LINES = args.workload == "lines"
-    B = args.batch or (6144 if LINES else 256)
+    B = args.batch or (12288 if LINES else 256)
     # ---- everything that forks worker processes happens BEFORE the GPU is touched: input frames and the CPU baseline
     gray256, depth8 = distinct_frames(W, H, "struct" if LINES else "desk", seed_for(rank))
     ND = len(gray256)
