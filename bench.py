@@ -238,7 +238,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=0, help="timed steps (default 20; 100 frames for dropin / 40 for tracking)")
     ap.add_argument("--warmup", type=int, default=-1, help="untimed warm-up steps (default 3; 10 frames for dropin / tracking)")
-    ap.add_argument("--batch", type=int, default=0, help="frames per step per GPU (default 12288 = two rounds of the 6144 wave slots of the LSD growing, ~225 GB of HBM; 256 for --workload orb)")
+    ap.add_argument("--batch", type=int, default=0, help="frames per step per GPU (default 12288 = two rounds of the 6144 wave slots of the LSD growing, 281 GB of HBM; 6144 per rank with N > 1; 256 for --workload orb)")
     ap.add_argument("--workload", choices=["orb", "lines", "dropin", "tracking"], default="lines",
                     help="lines = BASELINE configs[2], the configuration of the headline metric; orb = configs[1]; dropin = B = 1 through the "
                          "C++ consumer; tracking = configs[4] through the C++ consumer")
@@ -264,7 +264,10 @@ def main():
         return run_consumer(args)
 
     LINES = args.workload == "lines"
-    B = args.batch or (12288 if LINES else 256)
+    # 12288 frames per launch = two rounds of the 6144 wave slots of the LSD growing (+3.8 % frames/s over 6144: the launch lasts as long as
+    # its longest frames) and 281 GB of the GPU's 309 GB; with N > 1 the all-gather's receive buffers (world x batch x 85 KB, twice) do not
+    # fit beside that, so every rank runs 6144 frames per launch (~165 GB); the same with --host-io (pinned staging + record buffers: 295 GB at 12288)
+    B = args.batch or ((12288 if world == 1 and not args.host_io else 6144) if LINES else 256)
     # ---- everything that forks worker processes happens BEFORE the GPU is touched: input frames and the CPU baseline
     gray256, depth8 = distinct_frames(W, H, "struct" if LINES else "desk", seed_for(rank))
     ND = len(gray256)
@@ -457,6 +460,7 @@ def main():
                                     "extract + SearchByProjection(cur,last) match, " + io),
                        "frames_per_step_per_gpu": B, "distinct_frames_per_batch": int(min(B, ND)), "mean_keypoints": round(mean_kp, 1),
                        "mean_matches": round(mean_matches, 1), "host_io": bool(args.host_io), "streams": args.streams,
+                       "hbm_in_use_GB": round((torch.cuda.mem_get_info()[1] - torch.cuda.mem_get_info()[0]) / 1e9, 1),
                        "multi_gpu": ("independent stream per rank; per-frame result records (counts, keypoints, descriptors, point matches, keylines, LBD "
                                      "descriptors, line equations, line matches, fans, planes) packed and all-gathered with RCCL through the C ABI "
                                      f"({'pslfe_gather_all' if gather_kind == 'RecordGather' else 'torch.distributed all_gather_into_tensor'}), "
