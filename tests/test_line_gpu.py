@@ -363,6 +363,33 @@ def test_line_extractor_xcd_grid_ragged_batch():
     le.ctx.device_free(d_ptr)
 
 
+@pytest.mark.parametrize("w,h", [(633, 479), (321, 243), (1001, 437)])
+def test_line_extractor_odd_image_sizes(w, h):
+    """Sizes that are multiples of nothing: the scaled image's width is neither a multiple of the 64-pixel scan chunks nor of the
+    256-pixel scan trips (a chunk straddles two rows), tiles are ragged on both edges, rows are unaligned.  One frame (helper waves,
+    static singletons) and the same frame inside a 70-frame launch (neither) against the oracle, bit for bit."""
+    import psl_slam_amd as P
+    import oracle_lib
+    img = np.ascontiguousarray(_scene("struct", 6, 3, 1280, 960)[100:100 + h, 200:200 + w])
+    ref_seg = oracle_lib.lsd_detect(img)
+    ref = oracle_lib.line_extract(img, 200)
+    le = P.LINEextractor(1, 1.2, 200, 0.0)
+    seg = le.lsd_detect(img)
+    assert seg.shape == ref_seg.shape and (seg.view(np.uint32) == ref_seg.view(np.uint32)).all()
+    k1, d1, e1 = le(img)
+    assert k1.tobytes() == ref[0].tobytes() and (d1 == ref[1]).all() and e1.tobytes() == ref[2].tobytes()
+    assert len(ref[0]) > 5
+    nb = 70
+    frames = np.ascontiguousarray(np.stack([img] * nb, 0))
+    lb = P.LINEextractor(1, 1.2, 200, 0.0, max_batch=nb)
+    d_ptr, _ = lb.ctx.device_array(frames)
+    lb.extract_batch_device(d_ptr, nb, w, h, w, w * h)
+    for f in (0, 33, 69):
+        k, dsc, eq, st = lb.fetch(f)
+        assert st == 0 and k.tobytes() == k1.tobytes() and (dsc == d1).all() and eq.tobytes() == e1.tobytes(), f
+    lb.ctx.device_free(d_ptr)
+
+
 @pytest.mark.parametrize("nscenes", [2, 4])
 def test_merge_stage_more_segments_than_the_small_lds_instance(nscenes):
     """k_line_merge exists for 512 and 1024 lines in LDS, beyond that its working set is in HBM: segment lists of ~700 and
