@@ -532,13 +532,13 @@ int pslfe_glue_fetch(pslfe_glue* g, int frame, int nlines, double* lines3d, floa
 /* ---- batched many-frames mode across the GPUs of one node (BASELINE configs[3]) -----------------------
  * The reference has no counterpart (it is single-process, single-camera: src/System.cc:91-101); north_star asks for
  * independent frames / streams sharded over the 8 GPUs with RCCL over xGMI for the result gather.  Stream s -> rank
- * s mod world, no data-path collective; the one exchange is an all-gather of fixed-size per-frame RESULT RECORDS holding
- * what Tracking.cc reads of a Frame on this path.  Record (little endian, sections 16-byte aligned, zero padded):
+ * s mod world, no data-path collective; the one exchange is a gather (to the consuming rank, or to all) of fixed-size per-frame
+ * RESULT RECORDS holding what Tracking.cc reads of a Frame on this path.  Record (little endian, sections 16-byte aligned, zero padded):
  *   header  8 x int32: n_kp, n_match, n_kl, n_lmatch, n_fan, n_planes (true counts), flags (bit0 kps / bit1 lines / bit2 fans /
  *           bit3 planes truncated to the capacity), frame index inside the rank's batch
  *   kps     [kp_cap] PslKeyPoint    = mvKeys               desc   [kp_cap][32] = mDescriptors
  *   match   [kp_cap] int32          = ORBmatcher::SearchByProjection result (query i -> keypoint of this frame, -1 none; all kp_cap rows of the
- *                                     caller's buffer, which holds -1 beyond the query count)
+ *                                     caller's buffer, which holds -1 beyond the query count; rows beyond match_stride read -1)
  *   kls     [kl_cap] PslKeyLine     = mvKeylinesUn         ldesc  [kl_cap][32] = mLdesc
  *   lineEq  [kl_cap][3] f64         = mvKeyLineFunctions   lmatch [kl_cap] int32 = LSDmatcher::match result
  *   fans    [fan_cap][4] f32        = CPartiallyRecoverConnectivity rows (x, y, i, j)
@@ -566,19 +566,25 @@ int pslfe_record_pack_device(pslfe_ctx* ctx, const PslRecordCaps* caps, const Ps
 int pslfe_glue_planes_device(pslfe_glue* g, const float** d_planes, const int32_t** d_plane_lines, const int32_t** d_plane_counts,
                              int* plane_stride);
 
-/* RCCL all-gather of the records, one communicator per context.  RCCL is loaded at run time (librccl.so.1).
+/* RCCL gather of the records, one communicator per context.  RCCL is loaded at run time (librccl.so.1).
  *   pslfe_gather_unique_id  rank 0 obtains the 128-byte ncclUniqueId and hands it to the other ranks by whatever channel the
  *                           host has (MPI, a socket, torch.distributed, a file);
  *   pslfe_gather_create     ncclCommInitRank - collective: every rank calls it with the same id;
  *   pslfe_gather_all        d_recv[world][bytes_per_rank] <- every rank's d_send[bytes_per_rank]; runs on the gather's own
  *                           stream AFTER everything issued on the context's stream so far, so the next batch's kernels
  *                           overlap it; one exchange may be in flight;
- *   pslfe_gather_wait       host_blocking != 0: the host waits for the exchange; 0: the context's stream waits for it. */
+ *   pslfe_gather_to_root    the same towards ONE consuming rank (SURVEY.md §8e "ncclGather-by-send/recv"): rank `root` receives
+ *                           d_recv[world][bytes_per_rank] (its own part included), the other ranks only send and need no receive
+ *                           buffer (d_recv may be NULL there) - one group of ncclSend / ncclRecv; collective: every rank of the
+ *                           communicator calls it with the same root and bytes_per_rank;
+ *   pslfe_gather_wait       host_blocking != 0: the host waits for the exchange; 0: the context's stream waits for it (the host
+ *                           may read the received records only after a host-blocking wait). */
 typedef struct pslfe_gather pslfe_gather;
 int pslfe_gather_unique_id(uint8_t id[128]);
 int pslfe_gather_create(pslfe_ctx* ctx, int rank, int world, const uint8_t id[128], pslfe_gather** out);
 void pslfe_gather_destroy(pslfe_gather* g);
 int pslfe_gather_all(pslfe_gather* g, const void* d_send, size_t bytes_per_rank, void* d_recv);
+int pslfe_gather_to_root(pslfe_gather* g, const void* d_send, size_t bytes_per_rank, int root, void* d_recv);
 int pslfe_gather_wait(pslfe_gather* g, int host_blocking);
 int pslfe_gather_world(const pslfe_gather* g, int* rank, int* world);
 

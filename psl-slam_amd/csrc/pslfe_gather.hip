@@ -1,8 +1,9 @@
 // libpslfe: the batched many-frames mode across the GPUs of one node (BASELINE config 4). Product code.
 // Frames and whole streams are independent - stream s runs on rank s mod world, no data-path collective.  The one exchange
 // is the RESULT GATHER: every rank packs the results of its batch into fixed-size per-frame records and the records are
-// all-gathered with RCCL (ncclAllGather over xGMI), one communicator per context, on the gather's own stream so that the
-// next batch's kernels overlap the exchange.  Record = everything Tracking.cc reads of a Frame on this path:
+// gathered with RCCL over xGMI - to the consuming rank (pslfe_gather_to_root: one group of ncclSend / ncclRecv, only the root
+// holds world x batch records) or to every rank (pslfe_gather_all: ncclAllGather) -, one communicator per context, on the
+// gather's own stream so that the next batch's kernels overlap the exchange.  Record = everything Tracking.cc reads of a Frame on this path:
 //   {counts, mvKeys, mDescriptors, point matches, mvKeylinesUn, mLdesc, mvKeyLineFunctions, line matches, fans, mvPlanes,
 //    mvPlaneLineNo}; ~85 KB at 1000 points / 200 lines, i.e. 3.4 GB/s per rank at 40 k frames/s against 153 GB/s per xGMI link:
 //   the exchange is latency, not bandwidth - hence ONE collective per batch over all records, not one per frame or per array.
@@ -32,6 +33,13 @@ __device__ __forceinline__ void copy_words(uint8_t* dst, const uint8_t* src, int
     for (int64_t i = tid; i < bytes / 4; i += 256) d[i] = s[i];
 }
 
+// match / lmatch: `cap` int32 rows indexed by the query; rows the caller's buffer does not hold (stride < cap) read "no match" = -1
+__device__ __forceinline__ void copy_match(uint8_t* dst, const int32_t* src, int cap, int stride, int tid) {
+    int32_t* d = reinterpret_cast<int32_t*>(dst);
+    const int have = min(cap, stride);
+    for (int i = tid; i < cap; i += 256) d[i] = i < have ? src[i] : -1;
+}
+
 __global__ __launch_bounds__(256) void k_record_pack(PackArgs A, uint8_t* __restrict__ out) {
     const int f = blockIdx.x, tid = threadIdx.x;
     uint8_t* rec = out + (size_t)f * A.L.bytes;
@@ -51,11 +59,11 @@ __global__ __launch_bounds__(256) void k_record_pack(PackArgs A, uint8_t* __rest
     }
     if (S.d_kps) copy_words(rec + A.L.off_kps, reinterpret_cast<const uint8_t*>(S.d_kps) + (size_t)f * S.kp_stride * 28, (int64_t)c_kp * 28, tid);
     if (S.d_desc) copy_words(rec + A.L.off_desc, S.d_desc + (size_t)f * S.kp_stride * 32, (int64_t)c_kp * 32, tid);
-    if (S.d_match) copy_words(rec + A.L.off_match, reinterpret_cast<const uint8_t*>(S.d_match) + (size_t)f * S.match_stride * 4, (int64_t)min(A.caps.kp_cap, S.match_stride) * 4, tid);  // indexed by the query (= a keypoint of the previous frame): fixed size
+    if (S.d_match) copy_match(rec + A.L.off_match, S.d_match + (size_t)f * S.match_stride, A.caps.kp_cap, S.match_stride, tid);  // indexed by the query (= a keypoint of the previous frame): fixed size
     if (S.d_kls) copy_words(rec + A.L.off_kls, reinterpret_cast<const uint8_t*>(S.d_kls) + (size_t)f * S.kl_stride * 68, (int64_t)c_kl * 68, tid);
     if (S.d_ldesc) copy_words(rec + A.L.off_ldesc, S.d_ldesc + (size_t)f * S.kl_stride * 32, (int64_t)c_kl * 32, tid);
     if (S.d_lineEq) copy_words(rec + A.L.off_lineEq, reinterpret_cast<const uint8_t*>(S.d_lineEq) + (size_t)f * S.kl_stride * 24, (int64_t)c_kl * 24, tid);
-    if (S.d_lmatch) copy_words(rec + A.L.off_lmatch, reinterpret_cast<const uint8_t*>(S.d_lmatch) + (size_t)f * S.lmatch_stride * 4, (int64_t)min(A.caps.kl_cap, S.lmatch_stride) * 4, tid);
+    if (S.d_lmatch) copy_match(rec + A.L.off_lmatch, S.d_lmatch + (size_t)f * S.lmatch_stride, A.caps.kl_cap, S.lmatch_stride, tid);
     if (S.d_fans) copy_words(rec + A.L.off_fans, reinterpret_cast<const uint8_t*>(S.d_fans) + (size_t)f * S.fan_stride * 16, (int64_t)c_fan * 16, tid);
     if (S.d_planes) copy_words(rec + A.L.off_planes, reinterpret_cast<const uint8_t*>(S.d_planes) + (size_t)f * S.plane_stride * 16, (int64_t)c_pl * 16, tid);
     if (S.d_plane_lines) copy_words(rec + A.L.off_plane_lines, reinterpret_cast<const uint8_t*>(S.d_plane_lines) + (size_t)f * S.plane_stride * 8, (int64_t)c_pl * 8, tid);
@@ -66,6 +74,9 @@ struct NcclId { char internal[128]; };
 typedef int (*fn_get_id)(NcclId*);
 typedef int (*fn_init_rank)(void**, int, NcclId, int);
 typedef int (*fn_all_gather)(const void*, void*, size_t, int, void*, hipStream_t);
+typedef int (*fn_send)(const void*, size_t, int, int, void*, hipStream_t);
+typedef int (*fn_recv)(void*, size_t, int, int, void*, hipStream_t);
+typedef int (*fn_group)(void);
 typedef int (*fn_destroy)(void*);
 typedef const char* (*fn_errstr)(int);
 
@@ -74,6 +85,9 @@ struct Rccl {
     fn_get_id get_id = nullptr;
     fn_init_rank init_rank = nullptr;
     fn_all_gather all_gather = nullptr;
+    fn_send send = nullptr;            // ncclSend / ncclRecv / ncclGroupStart / ncclGroupEnd: pslfe_gather_to_root
+    fn_recv recv = nullptr;
+    fn_group group_start = nullptr, group_end = nullptr;
     fn_destroy destroy = nullptr;
     fn_errstr errstr = nullptr;
 };
@@ -91,6 +105,10 @@ Rccl* rccl() {
             R.get_id = (fn_get_id)dlsym(R.h, "ncclGetUniqueId");
             R.init_rank = (fn_init_rank)dlsym(R.h, "ncclCommInitRank");
             R.all_gather = (fn_all_gather)dlsym(R.h, "ncclAllGather");
+            R.send = (fn_send)dlsym(R.h, "ncclSend");
+            R.recv = (fn_recv)dlsym(R.h, "ncclRecv");
+            R.group_start = (fn_group)dlsym(R.h, "ncclGroupStart");
+            R.group_end = (fn_group)dlsym(R.h, "ncclGroupEnd");
             R.destroy = (fn_destroy)dlsym(R.h, "ncclCommDestroy");
             R.errstr = (fn_errstr)dlsym(R.h, "ncclGetErrorString");
             if (!R.get_id || !R.init_rank || !R.all_gather || !R.destroy) { dlclose(R.h); R.h = nullptr; }
@@ -116,7 +134,8 @@ struct pslfe_gather {
     void* comm = nullptr;
     hipStream_t stream = nullptr;   // the exchange runs here, ordered after the context's stream by ev_ready
     hipEvent_t ev_ready = nullptr, ev_done = nullptr;
-    bool pending = false;
+    bool pending = false;        // an exchange has been issued whose completion the HOST has not waited for
+    bool stream_waited = false;  // ... but the context's stream already waits for it (pslfe_gather_wait(g, 0))
 };
 
 extern "C" {
@@ -221,6 +240,34 @@ int pslfe_gather_all(pslfe_gather* g, const void* d_send, size_t bytes_per_rank,
     PSL_NCCL(R, R->all_gather(d_send, d_recv, bytes_per_rank, /* ncclInt8 */ 0, g->comm, g->stream));
     PSL_HIP(hipEventRecord(g->ev_done, g->stream));
     g->pending = true;
+    g->stream_waited = false;
+    return PSLFE_OK;
+}
+
+int pslfe_gather_to_root(pslfe_gather* g, const void* d_send, size_t bytes_per_rank, int root, void* d_recv) {
+    PSL_REQUIRE(g && d_send && bytes_per_rank > 0 && root >= 0 && root < g->world, PSLFE_E_INVALID, "pslfe_gather_to_root: bad argument (root %d of %d)", root, g ? g->world : 0);
+    PSL_REQUIRE(g->rank != root || d_recv, PSLFE_E_INVALID, "pslfe_gather_to_root: the root needs a receive buffer");
+    Rccl* R = rccl();
+    PSL_REQUIRE(R, PSLFE_E_NODEVICE, "pslfe_gather: librccl.so.1 could not be loaded");
+    PSL_REQUIRE(R->send && R->recv && R->group_start && R->group_end, PSLFE_E_NODEVICE, "pslfe_gather_to_root: this RCCL has no ncclSend / ncclRecv");
+    PSL_HIP(hipSetDevice(g->ctx->device));
+    PSL_HIP(hipEventRecord(g->ev_ready, g->ctx->stream));
+    PSL_HIP(hipStreamWaitEvent(g->stream, g->ev_ready, 0));
+    // ONE group: every rank sends its records to the root (the root to itself: RCCL turns a self send / recv pair into a device
+    // copy), the root posts one receive per rank.  A failure inside the group still closes it, so the communicator stays usable.
+    PSL_NCCL(R, R->group_start());
+    int e = R->send(d_send, bytes_per_rank, /* ncclInt8 */ 0, root, g->comm, g->stream);
+    if (e == 0 && g->rank == root)
+        for (int r = 0; r < g->world && e == 0; ++r)
+            e = R->recv(static_cast<uint8_t*>(d_recv) + (size_t)r * bytes_per_rank, bytes_per_rank, /* ncclInt8 */ 0, r, g->comm, g->stream);
+    const int e2 = R->group_end();
+    if (e != 0 || e2 != 0) {
+        pslfe_set_error("pslfe_gather_to_root: ncclSend / ncclRecv -> %s", R->errstr ? R->errstr(e != 0 ? e : e2) : "RCCL error");
+        return PSLFE_E_HIP;
+    }
+    PSL_HIP(hipEventRecord(g->ev_done, g->stream));
+    g->pending = true;
+    g->stream_waited = false;
     return PSLFE_OK;
 }
 
@@ -228,9 +275,13 @@ int pslfe_gather_wait(pslfe_gather* g, int host_blocking) {
     PSL_REQUIRE(g, PSLFE_E_INVALID, "pslfe_gather_wait: gather is NULL");
     if (!g->pending) return PSLFE_OK;
     PSL_HIP(hipSetDevice(g->ctx->device));
-    if (host_blocking) PSL_HIP(hipEventSynchronize(g->ev_done));
-    else PSL_HIP(hipStreamWaitEvent(g->ctx->stream, g->ev_done, 0));
-    g->pending = false;
+    if (host_blocking) {   // the host waits; only this clears `pending` (a stream-side wait before it does not make the host safe)
+        PSL_HIP(hipEventSynchronize(g->ev_done));
+        g->pending = false;
+    } else if (!g->stream_waited) {
+        PSL_HIP(hipStreamWaitEvent(g->ctx->stream, g->ev_done, 0));
+        g->stream_waited = true;
+    }
     return PSLFE_OK;
 }
 

@@ -250,7 +250,7 @@ struct pslfe_line {
         }
         {
             PSL_STAGE_BEGIN(ctx, "line.lsd_grad");
-            if (hipMemsetAsync(d_used, 0, (size_t)P.W * P.H * F, st) != hipSuccess) return PSLFE_E_HIP;  // the `used` map: 1 byte per scaled pixel
+            PSL_HIP(hipMemsetAsync(d_used, 0, (size_t)P.W * P.H * F, st));  // the `used` map: 1 byte per scaled pixel
             P.singles = F <= PSL_GROW_HELPER_FRAMES;
             P.full_grad = nframes == 1;  // pslfe_line_debug_gradient reads the whole magnitude image of a single-frame call
             const unsigned gx = (P.W + 63) / 64, gy = (P.H + PSL_GRAD_TH - 1) / PSL_GRAD_TH;

@@ -4,9 +4,11 @@ record / gather part of the C ABI (include/pslfe.h: pslfe_record_*, pslfe_gather
 Frames and whole streams are independent, so they are sharded with no data-path collective: stream s runs on rank
 s mod world.  The one exchange step is the RESULT GATHER: every rank packs the results of its batch into fixed-size per-frame
 records (counts, mvKeys, mDescriptors, point matches, mvKeylinesUn, mLdesc, mvKeyLineFunctions, line matches, fans, mvPlanes,
-mvPlaneLineNo; ~85 KB at 1000 points / 200 lines) and ONE all-gather per batch moves them:
-  * on the GPUs: pslfe_record_pack_device + pslfe_gather_all = ncclAllGather from RCCL over xGMI, issued from the C ABI on the
-    gather's own stream (RecordGather below; torch.distributed only carries the 128-byte ncclUniqueId and the barriers);
+mvPlaneLineNo; ~85 KB at 1000 points / 200 lines) and ONE gather per batch moves them:
+  * on the GPUs: pslfe_record_pack_device + pslfe_gather_to_root = one group of ncclSend / ncclRecv from RCCL over xGMI towards the
+    consuming rank (only that rank holds world x batch records; root=None: pslfe_gather_all = ncclAllGather to every rank), issued
+    from the C ABI on the gather's own stream (RecordGather below; torch.distributed only carries the 128-byte ncclUniqueId, the
+    agreement on which gather is used, and the barriers);
   * in the CPU tests: the same records, packed with numpy by the same layout (pslfe_record_layout is host arithmetic), moved by
     torch.distributed's gloo backend (ResultGather).
 """
@@ -99,25 +101,67 @@ class RecordLayout:
         return out
 
 
-class RecordGather:
-    """GPU path: pslfe_record_pack_device + pslfe_gather_all (RCCL).  Double-buffered: submit() packs this batch's records and
-    starts the all-gather on the gather's own stream; the previous exchange is waited for only when its buffers are reused."""
+def agree_all_ranks(ok, world, device=None):
+    """True iff `ok` holds on EVERY rank (all_reduce MIN over torch.distributed): decisions that select which collective the ranks
+    issue next must be taken together, or the ranks end up in different collectives and hang."""
+    if world == 1:
+        return bool(ok)
+    import torch
+    import torch.distributed as dist
+    t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device if device is not None else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return bool(int(t.item()))
 
-    def __init__(self, ctx, layout, nframes, rank, world, device, broadcast_id):
-        """broadcast_id(id_tensor_or_None) -> 128-byte uint8 numpy array on every rank (rank 0 passes the id it obtained)."""
+
+class RecordGather:
+    """GPU path: pslfe_record_pack_device + pslfe_gather_to_root / pslfe_gather_all (RCCL).  Double-buffered: submit() packs this
+    batch's records and starts the exchange on the gather's own stream; the previous exchange is waited for only when its buffers
+    are reused.  root = r: records go to rank r only (the others hold no receive buffer); root = None: all-gather to every rank."""
+
+    def __init__(self, ctx, layout, nframes, rank, world, device, broadcast_id, root=0, agree=None):
+        """broadcast_id(uid, ok) -> (128-byte uint8 numpy array, ok) as rank 0 holds them, on every rank; agree(ok) -> True iff ok on
+        every rank (default: agree_all_ranks).  COLLECTIVE and failure-safe: a rank that cannot load RCCL or create its communicator
+        does not raise before every rank has taken part in the same broadcast / agreement, so all ranks raise together (and the
+        caller can fall back to TorchRecordGather on all of them) instead of one rank leaving the others in a collective."""
         import torch
         import psl_slam_amd as P
-        self.P, self.ctx, self.layout, self.nframes, self.world = P, ctx, layout, nframes, world
+        self.P, self.ctx, self.layout, self.nframes, self.world, self.rank, self.root = P, ctx, layout, nframes, world, rank, root
+        agree = agree or (lambda ok: agree_all_ranks(ok, world, device))
         uid = np.zeros(128, np.uint8)
+        ok, err = True, ""
         if rank == 0:
-            P._check(P.lib().pslfe_gather_unique_id(P._ptr(uid)), "pslfe_gather_unique_id")
-        uid = np.ascontiguousarray(broadcast_id(uid), np.uint8)
+            rc = P.lib().pslfe_gather_unique_id(P._ptr(uid))
+            if rc != 0:
+                ok, err = False, f"pslfe_gather_unique_id: {P.lib().pslfe_last_error().decode()}"
+        uid, ok0 = broadcast_id(uid, ok)
         self._h = C.c_void_p()
-        P._check(P.lib().pslfe_gather_create(ctx._h, C.c_int(rank), C.c_int(world), P._ptr(uid), C.byref(self._h)), "pslfe_gather_create")
+        if ok0:
+            uid = np.ascontiguousarray(uid, np.uint8)
+            rc = P.lib().pslfe_gather_create(ctx._h, C.c_int(rank), C.c_int(world), P._ptr(uid), C.byref(self._h))
+            if rc != 0:
+                ok, err = False, f"pslfe_gather_create: {P.lib().pslfe_last_error().decode()}"
+        else:
+            ok, err = False, err or "rank 0 could not obtain an ncclUniqueId"
+        if not agree(ok):
+            self.close()
+            raise RuntimeError(err or "pslfe_gather could not be created on another rank")
         self.send = [torch.empty((nframes, layout.bytes), dtype=torch.uint8, device=device) for _ in range(2)]
-        self.recv = [torch.empty((world, nframes, layout.bytes), dtype=torch.uint8, device=device) for _ in range(2)]
+        self.recv = ([torch.empty((world, nframes, layout.bytes), dtype=torch.uint8, device=device) for _ in range(2)]
+                     if (root is None or rank == root) else [None, None])
         self.k = 0
         self.bytes_per_step = nframes * layout.bytes
+
+    def ranks_seen(self):
+        """The ranks of the communicator as the exchange itself reports them: every rank contributes its rank number through
+        pslfe_gather_all (4 bytes); returns the list every rank received."""
+        import torch
+        dev = self.send[0].device
+        s = torch.tensor([self.rank], dtype=torch.int32, device=dev)
+        r = torch.full((self.world,), -1, dtype=torch.int32, device=dev)
+        torch.cuda.current_stream(dev).synchronize()
+        self.P._check(self.P.lib().pslfe_gather_all(self._h, C.c_void_p(s.data_ptr()), C.c_size_t(4), C.c_void_p(r.data_ptr())), "pslfe_gather_all")
+        self.wait()
+        return [int(v) for v in r.cpu().numpy()]
 
     def submit(self, sources):
         P, k = self.P, self.k
@@ -125,8 +169,12 @@ class RecordGather:
         P._check(P.lib().pslfe_gather_wait(self._h, C.c_int(0)), "pslfe_gather_wait")
         P._check(P.lib().pslfe_record_pack_device(self.ctx._h, C.byref(self.layout.caps), C.byref(sources), C.c_int(self.nframes),
                                                   C.c_void_p(self.send[k].data_ptr())), "pslfe_record_pack_device")
-        P._check(P.lib().pslfe_gather_all(self._h, C.c_void_p(self.send[k].data_ptr()), C.c_size_t(self.bytes_per_step),
-                                          C.c_void_p(self.recv[k].data_ptr())), "pslfe_gather_all")
+        recv = C.c_void_p(self.recv[k].data_ptr()) if self.recv[k] is not None else C.c_void_p()
+        if self.root is None:
+            P._check(P.lib().pslfe_gather_all(self._h, C.c_void_p(self.send[k].data_ptr()), C.c_size_t(self.bytes_per_step), recv), "pslfe_gather_all")
+        else:
+            P._check(P.lib().pslfe_gather_to_root(self._h, C.c_void_p(self.send[k].data_ptr()), C.c_size_t(self.bytes_per_step),
+                                                  C.c_int(self.root), recv), "pslfe_gather_to_root")
         self.k ^= 1
         return k
 
@@ -145,16 +193,29 @@ class RecordGather:
 
 class TorchRecordGather:
     """Same interface as RecordGather, the exchange through torch.distributed (backend nccl = RCCL as well): the fallback when the
-    C ABI cannot load librccl on a node.  The pack kernel is the C ABI's either way."""
+    C ABI cannot load librccl on a node.  The pack kernel is the C ABI's either way.  root = r: dist.gather to rank r (receive
+    buffers only there); root = None: all_gather_into_tensor."""
 
-    def __init__(self, ctx, layout, nframes, world, device):
+    def __init__(self, ctx, layout, nframes, world, device, rank=0, root=0):
         import torch
         import psl_slam_amd as P
-        self.P, self.ctx, self.layout, self.nframes, self.world = P, ctx, layout, nframes, world
+        self.P, self.ctx, self.layout, self.nframes, self.world, self.rank, self.root = P, ctx, layout, nframes, world, rank, root
         self.send = [torch.empty((nframes, layout.bytes), dtype=torch.uint8, device=device) for _ in range(2)]
-        self.recv = [torch.empty((world, nframes, layout.bytes), dtype=torch.uint8, device=device) for _ in range(2)]
+        self.recv = ([torch.empty((world, nframes, layout.bytes), dtype=torch.uint8, device=device) for _ in range(2)]
+                     if (root is None or rank == root) else [None, None])
         self.work = [None, None]
         self.k = 0
+
+    def ranks_seen(self):
+        import torch
+        import torch.distributed as dist
+        if self.world == 1:
+            return [self.rank]
+        dev = self.send[0].device
+        s = torch.tensor([self.rank], dtype=torch.int32, device=dev)
+        r = torch.full((self.world,), -1, dtype=torch.int32, device=dev)
+        dist.all_gather_into_tensor(r, s)
+        return [int(v) for v in r.cpu().numpy()]
 
     def submit(self, sources):
         import torch.distributed as dist
@@ -163,7 +224,12 @@ class TorchRecordGather:
             self.work[k].wait()
         P._check(P.lib().pslfe_record_pack_device(self.ctx._h, C.byref(self.layout.caps), C.byref(sources), C.c_int(self.nframes),
                                                   C.c_void_p(self.send[k].data_ptr())), "pslfe_record_pack_device")
-        self.work[k] = dist.all_gather_into_tensor(self.recv[k].view(-1), self.send[k].view(-1), async_op=True) if self.world > 1 else None
+        if self.world == 1:
+            self.work[k] = None
+        elif self.root is None:
+            self.work[k] = dist.all_gather_into_tensor(self.recv[k].view(-1), self.send[k].view(-1), async_op=True)
+        else:
+            self.work[k] = dist.gather(self.send[k], list(self.recv[k].unbind(0)) if self.rank == self.root else None, dst=self.root, async_op=True)
         self.k ^= 1
         return k
 

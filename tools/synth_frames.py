@@ -6,7 +6,12 @@ edges) over a band-limited noise texture, viewed through a slowly drifting simil
 so that frame-to-frame matching is meaningful.  Depth = tilted plane, z in [0.8, 4] m, x5000 (u16).
 
 `style`: "desk"   polygons + noise sigma 6  (fr1_desk-like: many corners)
-         "struct" polygons + noise sigma 2  (fr3_structure_notexture-like: few corners, lines)
+         "struct" polygons + noise sigma 2  (fr3_structure_notexture-like: few corners, lines); the painter's order hides most
+                  edges: ~150 LSD segments and ~30 keylines of >= 50 px per frame with LSD_REFINE_ADV
+         "sticks" structure scene at the line load the configuration names (200 lines): thin high-contrast bars (4 - 6 px wide,
+                  58 - 80 px long, random orientation) placed WITHOUT overlap (2 px clearance), a 0.6 px point spread, noise
+                  sigma 1: ~370 LSD segments and 160 - 185 keylines of >= 50 px per frame with LSD_REFINE_ADV, four corners
+                  per bar for ORB (1000 keypoints)
 """
 import numpy as np
 
@@ -42,6 +47,9 @@ class Scene:
         # scene canvas is larger than the view so the drift never runs out of content
         self.cw, self.ch = int(w * 1.5), int(h * 1.5)
         polys = []
+        if style == "sticks":
+            polys = self._sticks(rng, scale)
+            n_poly = 0
         for _ in range(n_poly):
             cx, cy = rng.uniform(0, self.cw), rng.uniform(0, self.ch)
             if rng.random() < 0.5:  # rectangle, random rotation
@@ -56,10 +64,36 @@ class Scene:
                 pts = np.stack([cx + ra * np.cos(ang), cy + rb * np.sin(ang)], 1)
             polys.append((pts.astype(np.float64), float(rng.uniform(30, 225))))
         self.polys = polys
-        sigma = 6.0 if style == "desk" else 2.0
+        sigma = {"desk": 6.0, "sticks": 1.0}.get(style, 2.0)
         self.noise = _smooth_noise(rng, self.ch, self.cw, 1.2, sigma)
         self.bg = float(rng.uniform(90, 160))
         self.tx, self.ty, self.rot = rng.uniform(-2, 2), rng.uniform(-2, 2), np.deg2rad(rng.uniform(-0.3, 0.3))
+
+    def _sticks(self, rng, scale):
+        """Non-overlapping thin bars over the canvas (rejection sampling against an occupancy mask; 2 px clearance)."""
+        cw, ch = self.cw, self.ch
+        occ = np.zeros((ch, cw), bool)
+        want = int(400 * (cw * ch) / (640.0 * 480.0) / (scale * scale))
+        polys, tries = [], 0
+        while tries < want * 80 and len(polys) < want:
+            tries += 1
+            cx, cy = rng.uniform(0, cw), rng.uniform(0, ch)
+            L, Wd = rng.uniform(58, 80) * scale / 2, rng.uniform(4, 6) * scale / 2
+            th = rng.uniform(0, np.pi)
+            c, s = np.cos(th), np.sin(th)
+            r = int(np.ceil(L + Wd + 4 * scale))
+            x0, y0, x1, y1 = max(int(cx) - r, 0), max(int(cy) - r, 0), min(int(cx) + r + 1, cw), min(int(cy) + r + 1, ch)
+            if x0 >= x1 or y0 >= y1:
+                continue
+            yy, xx = np.mgrid[y0:y1, x0:x1]
+            u, v = (xx - cx) * c + (yy - cy) * s, -(xx - cx) * s + (yy - cy) * c
+            if (occ[y0:y1, x0:x1] & (np.abs(u) < L + 2 * scale) & (np.abs(v) < Wd + 2 * scale)).any():
+                continue
+            occ[y0:y1, x0:x1] |= (np.abs(u) < L) & (np.abs(v) < Wd)
+            pts = np.array([[-L, -Wd], [L, -Wd], [L, Wd], [-L, Wd]]) @ np.array([[c, s], [-s, c]]) + [cx, cy]
+            g = rng.uniform(20, 70) if rng.random() < 0.5 else rng.uniform(190, 240)
+            polys.append((pts.astype(np.float64), float(g)))
+        return polys
 
     def _view_to_canvas(self, t):
         """3x3 map from view pixel coords to canvas coords at frame t (drift <=2 px, <=0.3 deg per frame)."""
@@ -102,6 +136,9 @@ class Scene:
         yy, xx = np.mgrid[0:h, 0:w]
         sx = np.clip(np.rint(A[0, 0] * xx + A[0, 1] * yy + A[0, 2]).astype(int), 0, self.cw - 1)
         sy = np.clip(np.rint(A[1, 0] * xx + A[1, 1] * yy + A[1, 2]).astype(int), 0, self.ch - 1)
+        if self.style == "sticks":   # a camera's point spread: the rasteriser above is binary (LSD's NFA test rejects staircase edges)
+            from scipy.ndimage import gaussian_filter
+            img = gaussian_filter(img, 0.6)
         img += self.noise[sy, sx]
         return np.clip(np.rint(img), 0, 255).astype(np.uint8)
 
