@@ -90,6 +90,7 @@ STAGE_KERNELS = {
     "line.merge": [("k_line_merge<512>", 1), ("k_line_merge<1024>", 1)], "line.lbd_pre": [("k_lbd_pre", 1)], "line.lbd": [("k_lbd", 1)], "line.pair": [("k_lil_pair", 1)],
     "line.match": [("k_line_match_batch", 1)], "line.good": [("k_line_good", 1)], "line.planes": [("k_fans_planes", 1)],
 }
+PER_LAUNCH_STAGES = ("line.nfa_count", "line.nfa_eval")   # STAGE_BYTES_PER_FRAME is per launch for these (6 launches per step), per step otherwise
 STAGE_NAMES = ["orb.pyramid", "orb.fast", "orb.octree", "orb.blur", "orb.describe", "match.grid", "match.window", "line.lsd_scale",
                "line.lsd_grad", "line.lsd_grow", "line.nfa_count", "line.nfa_eval", "line.merge", "line.lbd_pre", "line.lbd", "line.pair", "line.match", "line.good",
                "line.planes", "gather.pack"]
@@ -122,9 +123,10 @@ def _gen_scene(args):
     return gray, depth
 
 
-def distinct_frames(w, h, style, seed0, nscenes=8, nt=32):
+def distinct_frames(w, h, style, seed0, nscenes=8, nt=32, serial=False):
     """(gray [nscenes*nt][h][w] u8, depth_u16 [nscenes][h][w]): the frames of a scene are consecutive (drift <= 2 px per frame), scenes
-    follow each other (a cut every nt frames).  Depth is a tilted plane per scene (x5000, TUM convention)."""
+    follow each other (a cut every nt frames).  Depth is a tilted plane per scene (x5000, TUM convention).  serial: no worker
+    processes (under a profiler whose preload has initialised the GPU this process must not fork)."""
     import multiprocessing as mp
     path = os.path.join(tempfile.gettempdir(), f"pslfe_bench_{w}x{h}_{style}_{seed0}_{nscenes}x{nt}.npz")
     if os.path.exists(path):
@@ -134,11 +136,15 @@ def distinct_frames(w, h, style, seed0, nscenes=8, nt=32):
         except Exception:
             pass
     jobs = [(w, h, style, seed0 + 17 * s, nt, 1.0 + 0.04 * s) for s in range(nscenes)]
-    try:
-        with mp.get_context("fork").Pool(min(nscenes, max(1, len(os.sched_getaffinity(0))))) as pool:
-            res = pool.map(_gen_scene, jobs)
-    except Exception:
+    if serial:
+        print("[bench] generating the input frames in this process (profiler preload present: no fork); a few minutes", file=sys.stderr, flush=True)
         res = [_gen_scene(j) for j in jobs]
+    else:
+        try:
+            with mp.get_context("fork").Pool(min(nscenes, max(1, len(os.sched_getaffinity(0))))) as pool:
+                res = pool.map(_gen_scene, jobs)
+        except Exception:
+            res = [_gen_scene(j) for j in jobs]
     gray = np.ascontiguousarray(np.concatenate([r[0] for r in res], 0))
     depth = np.stack([r[1] for r in res], 0)
     try:
@@ -152,8 +158,7 @@ def distinct_frames(w, h, style, seed0, nscenes=8, nt=32):
 def depth_f32(depth_u16):
     """imDepth.convertTo(imDepth, CV_32F, mDepthMapFactor) (src/Tracking.cc:230-235): u16 * (1 / 5000) in float - the same values
     pslfe_depth_to_float_device produces, so HBM-resident and --host-io runs see identical depth."""
-    import oracle_lib
-    return oracle_lib.depth_to_float(np.ascontiguousarray(depth_u16), np.float32(1.0) / np.float32(5000.0))
+    return np.ascontiguousarray(depth_u16).astype(np.float32) * (np.float32(1.0) / np.float32(5000.0))   # u16 -> f32 is exact, one f32 product
 
 
 class stdout_to_stderr:
@@ -233,21 +238,147 @@ def run_consumer(args):
     return 0
 
 
+def under_profiler():
+    """rocprofv3's preload initialises the GPU before this program starts (with --pmc it does): such a process must not fork."""
+    return "rocprof" in os.environ.get("LD_PRELOAD", "").lower() or any(k.startswith(("ROCPROF", "ROCP_TOOL")) for k in os.environ)
+
+
+def build_once():
+    """libpslfe.so is built by ONE process (the others wait on a file lock and find it up to date)."""
+    import fcntl
+    import psl_slam_amd as P
+    with open(os.path.join(tempfile.gettempdir(), "pslfe_build.lock"), "w") as lk:
+        fcntl.flock(lk, fcntl.LOCK_EX)
+        try:
+            P.build()
+        finally:
+            fcntl.flock(lk, fcntl.LOCK_UN)
+    return P
+
+
+def probe_device(local_rank):
+    """pslfe_ctx_create on this rank's device in a short-lived child process (this process forks worker pools before it touches
+    the GPU itself).  Returns None when the device is usable, else the library's message (PSLFE_E_NODEVICE: no CPU fallback)."""
+    import subprocess
+    code = ("import sys; sys.path.insert(0, %r); import psl_slam_amd as P\n"
+            "try:\n    P.Context(%d).close()\nexcept P.PslfeError as e:\n    print(str(e)); sys.exit(3)\n" % (ROOT, local_rank))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
+    if r.returncode == 0:
+        return None
+    return (r.stdout.strip() or r.stderr.strip() or f"exit code {r.returncode}").splitlines()[-1]
+
+
+# ---- python bench.py --gpus N without a launcher: this process starts the N ranks itself and never touches the GPU ------------
+def spawn_ranks(n, argv):
+    """One child process per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT in its environment, as
+    torch.distributed.run would set them), started BEFORE anything in this process has touched the GPU.  Rank 0's stdout - the one
+    JSON line - is relayed; every other rank's stdout goes to stderr.  Exit code = the worst of the children; when a rank dies the
+    others get 60 s to notice (a failed rendezvous or collective) and are then terminated by PID."""
+    import socket
+    import subprocess
+    import threading
+    build_once()   # hipcc only; no GPU call
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", PSLFE_BENCH_LAUNCHER="self")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=(r == 0)))
+    lines = []
+
+    def relay():
+        for line in procs[0].stdout:
+            lines.append(line)
+            sys.stdout.write(line)
+            sys.stdout.flush()
+    th = threading.Thread(target=relay, daemon=True)
+    th.start()
+    first_fail = None
+    while any(p.poll() is None for p in procs):
+        time.sleep(0.25)
+        bad = [p for p in procs if p.poll() not in (None, 0)]
+        if bad and first_fail is None:
+            first_fail = time.time()
+        if first_fail is not None and time.time() - first_fail > 60.0:
+            for p in procs:
+                if p.poll() is None:
+                    print(f"[bench] rank process {p.pid} still running 60 s after another rank failed: terminating it", file=sys.stderr)
+                    p.terminate()
+            time.sleep(5.0)
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+    th.join(timeout=10.0)
+    rcs = [p.returncode for p in procs]
+    worst = max((abs(rc) for rc in rcs), default=0)
+    if worst:
+        print(f"[bench] rank exit codes {rcs}", file=sys.stderr)
+    return min(worst, 255)
+
+
+def launcher_selftest(rank, world):
+    """CPU rehearsal of the N > 1 choreography with the gloo backend (tests/test_multigpu_cpu.py drives it through spawn_ranks):
+    rendezvous, the collective agreement that selects the gather, gather-to-rank-0 of per-rank record buffers, barrier-bracketed
+    timing with MAX over ranks, one JSON line from rank 0.  No product code path runs here - there is no CPU path to run."""
+    import zlib
+    import torch
+    import torch.distributed as dist
+    from importlib import import_module
+    mg = import_module("psl_slam_amd.multigpu")
+    dist.init_process_group("gloo")
+    fail_rank = int(os.environ.get("PSLFE_SELFTEST_FAIL_RANK", "-1"))      # this rank "cannot create its communicator"
+    agreed = mg.agree_all_ranks(rank != fail_rank, world)
+    rng = np.random.default_rng(100 + rank)
+    rec = torch.from_numpy(rng.integers(0, 256, (16, 4096), dtype=np.uint8))
+    recv = [torch.empty_like(rec) for _ in range(world)] if rank == 0 else None
+    dist.barrier()
+    t0 = time.perf_counter()
+    dist.gather(rec, recv, dst=0)
+    dist.barrier()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    seen = torch.full((world,), -1, dtype=torch.int32)
+    dist.all_gather_into_tensor(seen, torch.tensor([rank], dtype=torch.int32))
+    if rank == 0:
+        want = [zlib.crc32(np.random.default_rng(100 + r).integers(0, 256, (16, 4096), dtype=np.uint8).tobytes()) for r in range(world)]
+        got = [zlib.crc32(r_.numpy().tobytes()) for r_ in recv]
+        print(json.dumps({"launcher_selftest": True, "n_gpus": world, "ranks_seen": [int(v) for v in seen], "gather_ok": got == want,
+                          "rccl_gather_agreed": agreed, "launcher": os.environ.get("PSLFE_BENCH_LAUNCHER", "external"),
+                          "max_s": float(t.item())}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=0, help="timed steps (default 20; 100 frames for dropin / 40 for tracking)")
     ap.add_argument("--warmup", type=int, default=-1, help="untimed warm-up steps (default 3; 10 frames for dropin / tracking)")
-    ap.add_argument("--batch", type=int, default=0, help="frames per step per GPU (default 12288 = two rounds of the 6144 wave slots of the LSD growing, 281 GB of HBM; 6144 per rank with N > 1; 256 for --workload orb)")
+    ap.add_argument("--batch", type=int, default=0, help="frames per step per GPU (default 12288 = two rounds of the 6144 wave slots of the LSD growing when the "
+                                                         "GPU's free memory holds it, for every N; else 6144; 256 for --workload orb)")
     ap.add_argument("--workload", choices=["orb", "lines", "dropin", "tracking"], default="lines",
                     help="lines = BASELINE configs[2], the configuration of the headline metric; orb = configs[1]; dropin = B = 1 through the "
                          "C++ consumer; tracking = configs[4] through the C++ consumer")
+    ap.add_argument("--scene", choices=["sticks", "struct", "desk"], default=None,
+                    help="synthetic scene family (tools/synth_frames.py).  lines: 'sticks' (default: the structure scene at the configured line load, "
+                         "160 - 185 keylines per frame) or 'struct' (rounds 1 - 2: ~29 keylines per frame); orb: 'desk'")
     ap.add_argument("--streams", type=int, default=1, choices=[1, 2],
                     help="2: the line pipeline on its own context / stream beside the ORB pipeline (the two extractor objects of a Frame are "
                          "independent); stages then overlap and their event timings stop meaning what they say, so 1 is the default")
     ap.add_argument("--host-io", action="store_true", help="host gray + depth in, host result records out, inside the timed region")
+    ap.add_argument("--gather", choices=["root", "all"], default="root",
+                    help="N > 1: per-frame result records to rank 0 (pslfe_gather_to_root: ncclSend / ncclRecv) or to every rank (pslfe_gather_all)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-like-for-like", action="store_true", help="skip the extra steps at 6144 frames per launch after the timed region")
+    ap.add_argument("--lookahead", type=int, default=1, help="dropin / tracking: frames extracted per launch by the FramePrefetcher (1 = one frame at a time)")
     ap.add_argument("--parity-frames", type=int, default=8)
+    ap.add_argument("--launcher-selftest", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--prepare-inputs", action="store_true", help="generate (and cache in /tmp) the input frames of the workload, then exit: run before profiler passes")
     args = ap.parse_args()
     consumer = args.workload in ("dropin", "tracking")
     if args.steps <= 0:
@@ -255,24 +386,40 @@ def main():
     if args.warmup < 0:
         args.warmup = 10 if consumer else 3
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return spawn_ranks(args.gpus, sys.argv[1:])          # no launcher: start the ranks here; this process never touches the GPU
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE {world}"
+    if world != args.gpus:
+        print(f"[bench] --gpus {args.gpus} but the launcher's WORLD_SIZE is {world}: running {world} ranks", file=sys.stderr)
+    if args.launcher_selftest:
+        return launcher_selftest(rank, world)
+    profiled = under_profiler()   # the profiler's preload owns the GPU already: this process starts no child process at all
+    if args.prepare_inputs:
+        distinct_frames(W, H, args.scene or ("sticks" if args.workload == "lines" else "desk"), seed_for(rank))
+        return 0
+    if profiled:
+        import psl_slam_amd as P
+    else:
+        P = build_once()
+    msg = None if profiled else probe_device(local_rank)
+    if msg is not None:
+        print(f"[bench] rank {rank}: {msg}", file=sys.stderr, flush=True)
+        return 3
     if consumer:
-        assert world == 1, "the single-frame workloads run on one GPU"
+        if world != 1:
+            print("[bench] the single-frame workloads run on one GPU", file=sys.stderr)
+            return 2
         return run_consumer(args)
 
     LINES = args.workload == "lines"
-    # 12288 frames per launch = two rounds of the 6144 wave slots of the LSD growing (+3.8 % frames/s over 6144: the launch lasts as long as
-    # its longest frames) and 281 GB of the GPU's 309 GB; with N > 1 the all-gather's receive buffers (world x batch x 85 KB, twice) do not
-    # fit beside that, so every rank runs 6144 frames per launch (~165 GB); the same with --host-io (pinned staging + record buffers: 295 GB at 12288)
-    B = args.batch or ((12288 if world == 1 and not args.host_io else 6144) if LINES else 256)
+    scene = args.scene or ("sticks" if LINES else "desk")
     # ---- everything that forks worker processes happens BEFORE the GPU is touched: input frames and the CPU baseline
-    gray256, depth8 = distinct_frames(W, H, "struct" if LINES else "desk", seed_for(rank))
+    gray256, depth8 = distinct_frames(W, H, scene, seed_for(rank), serial=profiled)
     ND = len(gray256)
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not profiled:
         import cpu_baseline as CB
         d32 = depth_f32(depth8[0])
         cpu = CB.run(gray256[:64], np.broadcast_to(d32, (64,) + d32.shape), NFEATURES, 200, LINES, budget_s=20.0, min_frames=200, warm=10)
@@ -286,11 +433,32 @@ def main():
         with stdout_to_stderr():
             dist.init_process_group("nccl", device_id=dev)
 
-    import psl_slam_amd as P
     from importlib import import_module
     import batch_pipeline as BP
     mg = import_module("psl_slam_amd.multigpu")
-    P.build()
+
+    # Frames per launch.  12288 = two rounds of the 6144 wave slots of the LSD growing (+3.8 % frames/s over 6144: the launch lasts as long
+    # as its longest frames) when the device's FREE memory holds it: 22.9 MB per frame (pipeline buffers 19.5 + 4.4, gray, depth f32) +
+    # the gather's buffers (N > 1: two send buffers per rank, ONE receive buffer of world x batch records on rank 0; --host-io: pinned
+    # staging is host memory, the u16 depth copy 0.6 MB per frame) + 6 GB of slack.  Every rank takes the same decision (MIN over ranks).
+    REC_BYTES = 85248
+    def need_bytes(b):
+        n = b * 22.9e6 + 6e9
+        if world > 1 or args.host_io:
+            n += 2 * b * REC_BYTES + (world * b * REC_BYTES * (1 if args.gather == "root" else 2) if world > 1 else 0)
+        if args.host_io:
+            n += b * W * H * 2
+        return n
+    if args.batch:
+        B = args.batch
+    elif not LINES:
+        B = 256
+    else:
+        free_b = torch.cuda.mem_get_info(dev)[0]
+        ok = mg.agree_all_ranks(free_b >= need_bytes(12288), world, dev)
+        B = 12288 if ok else 6144
+        if not ok and rank == 0:
+            print(f"[bench] {free_b / 1e9:.1f} GB free on the device: 6144 frames per launch instead of 12288", file=sys.stderr)
 
     # a real (non-null) torch stream: the library launches on it, so torch ops and the HIP kernels are ordered on one stream and
     # torch.cuda events / synchronize see everything
@@ -316,11 +484,13 @@ def main():
             host_io["d_depth16"] = torch.empty((B, H, W), dtype=torch.int16, device=dev)
 
     gather = None
-    gather_kind = None
+    gather_info = None
     layout = None
     rec_host = None
+    nB = [B]   # frames per launch of step(): B, or 6144 for the like-for-like steps after the timed region
 
     def step():
+        n = nB[0]
         if host_io is not None:   # H2D inside the step; depth arrives as the sensor's u16 and is converted on the device (src/Tracking.cc:230-235)
             frames_d.copy_(host_io["gray"], non_blocking=True)
             if LINES:
@@ -330,10 +500,10 @@ def main():
                                                              __import__("ctypes").c_void_p(depth_d.data_ptr())), "pslfe_depth_to_float_device")
         if stream_l is not None:
             stream_l.wait_stream(stream)     # the inputs (and the previous step's record pack) are ordered on the main stream
-        pipe.step(frames_d.data_ptr(), depth_d.data_ptr() if LINES else None)
+        pipe.step(frames_d.data_ptr(), depth_d.data_ptr() if LINES else None, n)
         if stream_l is not None:
             stream.wait_stream(stream_l)     # join: the step ends when both pipelines have
-        if gather is not None:
+        if gather is not None and n == B:
             k = gather.submit(pipe.record_sources(mg))
             if rec_host is not None:   # D2H of this rank's packed records inside the step
                 rec_host.copy_(gather.send[k], non_blocking=True)
@@ -344,22 +514,29 @@ def main():
     torch.cuda.synchronize(dev)
     if world > 1 or args.host_io:
         layout = pipe.record_layout(mg)
+        assert layout.bytes == REC_BYTES or not LINES, layout.bytes
+        root = None if args.gather == "all" else 0
 
-        def bcast(uid):
+        def bcast(uid, ok):   # rank 0's 128-byte ncclUniqueId and whether it got one, to every rank (always the SAME collective on all ranks)
             if world == 1:
-                return uid
-            t = torch.from_numpy(uid.copy()).to(dev)
+                return uid, ok
+            t = torch.from_numpy(np.concatenate([uid, np.array([1 if ok else 0], np.uint8)])).to(dev)
             dist.broadcast(t, 0)
-            return t.cpu().numpy()
+            a = t.cpu().numpy()
+            return a[:128].copy(), bool(a[128])
         with stdout_to_stderr():
             try:
-                gather = mg.RecordGather(ctx, layout, B, rank, world, dev, bcast)
-            except Exception as e:   # RCCL not loadable through the C ABI on this node: the same records through torch.distributed
-                print(f"[bench] pslfe_gather unavailable ({e}); gathering the records with torch.distributed", file=sys.stderr)
-                gather = mg.TorchRecordGather(ctx, layout, B, world, dev)
-            gather_kind = type(gather).__name__
+                gather = mg.RecordGather(ctx, layout, B, rank, world, dev, bcast, root=root, recv_slots=1 if root is not None else 2)
+                kind = "pslfe_gather_to_root (one group of ncclSend / ncclRecv, RCCL through the C ABI)" if root is not None else "pslfe_gather_all (ncclAllGather, RCCL through the C ABI)"
+            except Exception as e:   # taken on EVERY rank together (RecordGather agrees before it raises): the same records through torch.distributed
+                print(f"[bench] rank {rank}: pslfe_gather unavailable ({e}); gathering the records with torch.distributed", file=sys.stderr)
+                gather = mg.TorchRecordGather(ctx, layout, B, world, dev, rank=rank, root=root, recv_slots=1 if root is not None else 2)
+                kind = "torch.distributed " + ("gather" if root is not None else "all_gather_into_tensor") + " (backend nccl = RCCL)"
             step()   # the first exchange initialises the communicator's channels
             gather.wait()
+            seen = gather.ranks_seen()
+        gather_info = {"kind": kind, "root": root, "record_bytes": int(layout.bytes), "ranks_seen": seen,
+                       "hardware_status": ("N > 1 exchange first exercised by this run" if world > 1 else "world-size-1 communicator")}
         if args.host_io:
             rec_host = torch.empty((B, layout.bytes), dtype=torch.uint8).pin_memory()
 
@@ -417,10 +594,28 @@ def main():
             ref = BP.oracle_frame((int(idx[pf]), gray256[idx[pf]]), (int(idx[f]), gray256[idx[f]]), dep, f, W, H, LINES, cam, cache=cache)
             BP.compare_frame(got, ref, f"bench frame {f} (distinct frame {int(idx[f])}): ")
             nchk += 1
-        if gather is not None and world == 1:   # and the packed record that went to the host is that frame
+        if gather is not None and rec_host is not None:   # and the packed record that went to the host is that frame
             u = layout.unpack(rec_host[cand[-1]].numpy())
             g = pipe.fetch_frame(cand[-1])
             assert u["kps"].tobytes() == g["kps"].tobytes() and u["n_match"] == g["nmatches"], "host record differs from the fetched frame"
+        if gather is not None and world > 1 and gather.recv[0] is not None:   # what rank 0 received from itself is its own last frame
+            got_rec = layout.unpack(gather.result(gather.k ^ 1)[0, B - 1].cpu().numpy())
+            g = pipe.fetch_frame(B - 1)
+            assert got_rec["kps"].tobytes() == g["kps"].tobytes() and got_rec["n_kl"] == len(g.get("kls", [])), "gathered record differs from the fetched frame"
+
+    # what the line stages worked on (the step's results are still in place): keylines, the LBD's sample count, fans, matches
+    line_load = None
+    if LINES:
+        d_kls, _, _, d_nkl, klcap = pipe.le.results_device()
+        nkl = torch.as_tensor(P._DevArray(d_nkl, (B,), "<i4"), device=dev)[:ND].clone()
+        kl = torch.as_tensor(P._DevArray(d_kls, (B, klcap, 17), "<i4"), device=dev)[:ND, :, 16]   # PslKeyLine.numOfPixels
+        live = torch.arange(klcap, device=dev)[None, :] < nkl[:, None]
+        npx = (kl * live).sum(1).double()
+        d_fans, d_nfans = pipe.le.fans_device()
+        nfans = torch.as_tensor(P._DevArray(d_nfans, (B,), "<i4"), device=dev)[:ND].double()
+        line_load = {"mean_keylines": round(float(nkl.double().mean().item()), 1), "mean_fans": round(float(nfans.mean().item()), 1),
+                     "mean_lbd_pixels_per_line": round(float((npx.sum() / max(1, int(nkl.sum().item()))).item()), 1),
+                     "lbd_sample_bytes_per_frame": int(round(float(npx.mean().item()) * 63 * 4))}
 
     # per-stage table: a few extra steps after the timed region, every stage timed
     for c in pipe.contexts():
@@ -432,54 +627,104 @@ def main():
         gather.wait()
     torch.cuda.synchronize(dev)
     stages = read_stages(min(args.steps, 5))
-    for c in pipe.contexts():
-        c.profile(False)
     stages[dom] = dom_stage
     counts = torch.as_tensor(P.orb_results_as_arrays(pipe.orb, B)[2], device=dev)
     mean_kp = float(counts.float().mean().item())
     mean_matches = float(pipe.nmatches.float().mean().item())
+    mean_lm = float(pipe.lnm.float().mean().item()) if LINES else 0.0
+
+    # like for like with rounds 1 - 2 and with runs that do not get 12288 frames into memory: 6144 frames per launch, 5 steps, untimed stages
+    lfl = None
+    if LINES and B > 6144 and not args.no_like_for_like and stream_l is None:
+        for c in pipe.contexts():
+            c.profile(False)
+        nB[0] = 6144
+        step()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        for _ in range(5):
+            step()
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        d1 = time.perf_counter() - t1
+        if world > 1:
+            t = torch.tensor([d1], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            d1 = float(t.item())
+        lfl = {"frames_per_step_per_gpu": 6144, "steps": 5, "value": round(world * 6144 * 5 / d1, 1), "unit": "frames/s", "ms_per_step": round(d1 / 5 * 1e3, 3),
+               "note": "same pipeline object, 6144 frames per launch (no gather in these steps)"}
+        nB[0] = B
+    segs = None
+    if LINES and rank == 0:   # LSD segments in front of the merging, on 16 of the distinct frames (single-frame entry point)
+        le1 = P.LINEextractor(1, 1.2, 200, 0.0, ctx=ctx)
+        segs = round(float(np.mean([len(le1.lsd_detect(gray256[i])) for i in range(0, ND, max(1, ND // 16))])), 1)
+        le1.close()
+    for c in pipe.contexts():
+        c.profile(False)
 
     if rank == 0:
         fps = world * B * args.steps / dt
-        dom_bytes = STAGE_BYTES_PER_FRAME[dom] * B
+        stage_bytes = dict(STAGE_BYTES_PER_FRAME)
+        line_bytes = LINE_BYTES_PER_FRAME
+        if line_load is not None:   # the LBD's gathers from the MEASURED sum of numOfPixels x 63 rows x 4 B instead of NL = 200, L = 100
+            stage_bytes["line.lbd"] = line_load["lbd_sample_bytes_per_frame"] + 100 * int(round(line_load["mean_keylines"]))
+            line_bytes = LINE_BYTES_PER_FRAME - (5040000 + 20000) + stage_bytes["line.lbd"]
+        dom_bytes = stage_bytes[dom] * B
         dom_s = stages[dom]["ms_per_launch"] * 1e-3
         achieved = dom_bytes / dom_s / 1e9
-        traffic, traffic_src = pmc_traffic(args.workload, dom, B)
-        per_frame = ORB_BYTES_PER_FRAME + MATCH_BYTES_PER_FRAME + (LINE_BYTES_PER_FRAME if LINES else 0)
+        traffic, traffic_src = pmc_traffic(args.workload + ("" if scene in ("sticks", "desk") else "_" + scene), dom, B)
+        per_frame = ORB_BYTES_PER_FRAME + MATCH_BYTES_PER_FRAME + (line_bytes if LINES else 0)
         io = ("host gray + depth(u16) in, host result records out inside the timed region" if args.host_io else "frames resident in HBM")
+        scene_txt = {"sticks": "synthetic structure scene at the configured line load ('sticks': non-overlapping high-contrast bars)",
+                     "struct": "synthetic structure-notexture-like stream ('struct': overlapping polygons, the scene of rounds 1 - 2)",
+                     "desk": "synthetic RGB-D stream (desk-like)"}[scene]
         out = {
             "metric": ("frames/sec ORB+line extract+match, 640x480 RGB-D, 1/2/4/8 MI355X" if LINES
                        else "frames/sec ORB-only extract+match, 640x480 RGB-D (BASELINE configs[1])"),
             "value": round(fps, 1), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": ("configs[2]: 640x480 synthetic structure-notexture-like stream, ORB 1000/1.2/8 FAST 20/7 + LSD (LSD_REFINE_ADV) / merge / LBD 200 lines "
+            "config": {"workload": (f"configs[2]: 640x480 {scene_txt}, ORB 1000/1.2/8 FAST 20/7 + LSD (LSD_REFINE_ADV) / merge / top-200 / LBD "
                                     "+ LIL pairing + RGB-D line glue (isLineGood, crossings, planes) extract, SearchByProjection(cur,last) + LSDmatcher::match, "
                                     + io) if LINES else
-                                   ("configs[1]: 640x480 synthetic RGB-D stream (desk-like), ORB 1000/1.2/8 FAST 20/7 "
+                                   (f"configs[1]: 640x480 {scene_txt}, ORB 1000/1.2/8 FAST 20/7 "
                                     "extract + SearchByProjection(cur,last) match, " + io),
-                       "frames_per_step_per_gpu": B, "distinct_frames_per_batch": int(min(B, ND)), "mean_keypoints": round(mean_kp, 1),
+                       "scene": scene, "frames_per_step_per_gpu": B, "distinct_frames_per_batch": int(min(B, ND)), "mean_keypoints": round(mean_kp, 1),
                        "mean_matches": round(mean_matches, 1), "host_io": bool(args.host_io), "streams": args.streams,
                        "hbm_in_use_GB": round((torch.cuda.mem_get_info()[1] - torch.cuda.mem_get_info()[0]) / 1e9, 1),
-                       "multi_gpu": ("independent stream per rank; per-frame result records (counts, keypoints, descriptors, point matches, keylines, LBD "
-                                     "descriptors, line equations, line matches, fans, planes) packed and all-gathered with RCCL through the C ABI "
-                                     f"({'pslfe_gather_all' if gather_kind == 'RecordGather' else 'torch.distributed all_gather_into_tensor'}), "
-                                     f"{layout.bytes} B per frame") if world > 1 else "single GPU"},
+                       "launcher": os.environ.get("PSLFE_BENCH_LAUNCHER", "torch.distributed.run" if "TORCHELASTIC_RUN_ID" in os.environ else "none"),
+                       "multi_gpu": ("independent stream per rank, no data-path collective; per-frame result records (counts, keypoints, descriptors, point "
+                                     "matches, keylines, LBD descriptors, line equations, line matches, fans, planes) packed on the device and gathered "
+                                     f"per batch: {gather_info['kind']}") if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": dom_bytes, "ms_per_launch": round(stages[dom]["ms_per_launch"], 4)},
             "pipeline_roofline": {"bytes_per_frame": per_frame,
                                   "achieved_GBs": round(fps / world * per_frame / 1e9, 2),
-                                  "frac_of_8TBs": round(fps / world * per_frame / 1e9 / HBM_PEAK_GBS, 5)},
+                                  "frac_of_8TBs": round(fps / world * per_frame / 1e9 / HBM_PEAK_GBS, 5),
+                                  "note": "SURVEY.md §8(d)'s accounting with the LBD term taken from the measured keylines of this workload"},
             "stages_ms_per_launch": {k: round(v["ms_per_launch"], 4) for k, v in stages.items()},
             "stages_ms_per_step": {k: round(v["ms_per_launch"] * v["launches"] / max(1, v["steps"]), 4) for k, v in stages.items()},
+            # algorithmic bytes of a stage (per launch for the NFA stages, whose table entry is per launch; per step otherwise) / its time
+            "stages_frac_of_hbm_peak": {k: round(stage_bytes[k] * B / ((v["ms_per_launch"] if k in PER_LAUNCH_STAGES else
+                                                                        v["ms_per_launch"] * v["launches"] / max(1, v["steps"])) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                                        for k, v in stages.items() if k in stage_bytes and v["ms_per_launch"] > 0},
             "parity_checked_frames": nchk,
         }
+        if gather_info is not None:
+            out["gather"] = gather_info
+        if lfl is not None:
+            out["like_for_like"] = lfl
         if cpu is not None:
             out["cpu_baseline"] = cpu
         if LINES:
-            out["config"]["mean_line_matches"] = round(float(pipe.lnm.float().mean().item()), 1)
+            out["config"]["mean_line_matches"] = round(mean_lm, 1)
             out["config"]["lsd_refine"] = "LSD_REFINE_ADV"
+            out["config"].update(line_load)
+            out["config"]["mean_segments"] = segs
         print(json.dumps(out), flush=True)
     if gather is not None:
         gather.close()

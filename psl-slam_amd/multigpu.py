@@ -118,9 +118,10 @@ class RecordGather:
     batch's records and starts the exchange on the gather's own stream; the previous exchange is waited for only when its buffers
     are reused.  root = r: records go to rank r only (the others hold no receive buffer); root = None: all-gather to every rank."""
 
-    def __init__(self, ctx, layout, nframes, rank, world, device, broadcast_id, root=0, agree=None):
+    def __init__(self, ctx, layout, nframes, rank, world, device, broadcast_id, root=0, agree=None, recv_slots=2):
         """broadcast_id(uid, ok) -> (128-byte uint8 numpy array, ok) as rank 0 holds them, on every rank; agree(ok) -> True iff ok on
-        every rank (default: agree_all_ranks).  COLLECTIVE and failure-safe: a rank that cannot load RCCL or create its communicator
+        every rank (default: agree_all_ranks); recv_slots = 1: one receive buffer (exchanges run in order on the gather's stream, so
+        they never overlap each other; the consumer must be done with result(k) before the next submit).  COLLECTIVE and failure-safe: a rank that cannot load RCCL or create its communicator
         does not raise before every rank has taken part in the same broadcast / agreement, so all ranks raise together (and the
         caller can fall back to TorchRecordGather on all of them) instead of one rank leaving the others in a collective."""
         import torch
@@ -146,8 +147,10 @@ class RecordGather:
             self.close()
             raise RuntimeError(err or "pslfe_gather could not be created on another rank")
         self.send = [torch.empty((nframes, layout.bytes), dtype=torch.uint8, device=device) for _ in range(2)]
-        self.recv = ([torch.empty((world, nframes, layout.bytes), dtype=torch.uint8, device=device) for _ in range(2)]
-                     if (root is None or rank == root) else [None, None])
+        self.recv = [None, None]
+        if root is None or rank == root:
+            r0 = torch.empty((world, nframes, layout.bytes), dtype=torch.uint8, device=device)
+            self.recv = [r0, r0 if recv_slots == 1 else torch.empty_like(r0)]
         self.k = 0
         self.bytes_per_step = nframes * layout.bytes
 
@@ -196,13 +199,15 @@ class TorchRecordGather:
     C ABI cannot load librccl on a node.  The pack kernel is the C ABI's either way.  root = r: dist.gather to rank r (receive
     buffers only there); root = None: all_gather_into_tensor."""
 
-    def __init__(self, ctx, layout, nframes, world, device, rank=0, root=0):
+    def __init__(self, ctx, layout, nframes, world, device, rank=0, root=0, recv_slots=2):
         import torch
         import psl_slam_amd as P
         self.P, self.ctx, self.layout, self.nframes, self.world, self.rank, self.root = P, ctx, layout, nframes, world, rank, root
         self.send = [torch.empty((nframes, layout.bytes), dtype=torch.uint8, device=device) for _ in range(2)]
-        self.recv = ([torch.empty((world, nframes, layout.bytes), dtype=torch.uint8, device=device) for _ in range(2)]
-                     if (root is None or rank == root) else [None, None])
+        self.recv = [None, None]
+        if root is None or rank == root:
+            r0 = torch.empty((world, nframes, layout.bytes), dtype=torch.uint8, device=device)
+            self.recv = [r0, r0 if recv_slots == 1 else torch.empty_like(r0)]
         self.work = [None, None]
         self.k = 0
 
@@ -226,6 +231,7 @@ class TorchRecordGather:
                                                   C.c_void_p(self.send[k].data_ptr())), "pslfe_record_pack_device")
         if self.world == 1:
             self.work[k] = None
+            self.recv[k][0].copy_(self.send[k], non_blocking=True)
         elif self.root is None:
             self.work[k] = dist.all_gather_into_tensor(self.recv[k].view(-1), self.send[k].view(-1), async_op=True)
         else:

@@ -1,6 +1,7 @@
 """Row (e) on one GPU: the batch step's results packed into per-frame records by pslfe_record_pack_device and moved by
-pslfe_gather_all - a real ncclAllGather from RCCL with a communicator of world size 1 (a one-GPU box has no peers; the N > 1
-exchange is the same call).  Records are compared with the per-frame fetch entry points, with the numpy packer the CPU (gloo)
+pslfe_gather_to_root (one group of ncclSend / ncclRecv - with a world of one the root's send to itself, the same calls every rank
+issues) and pslfe_gather_all (ncclAllGather) - real RCCL with a communicator of world size 1 (a one-GPU box has no peers; the
+N > 1 exchange is the same call).  Records are compared with the per-frame fetch entry points, with the numpy packer the CPU (gloo)
 test uses, and, through those, with the CPU oracle."""
 import numpy as np
 import pytest
@@ -10,7 +11,8 @@ import synth_frames as sf
 pytestmark = pytest.mark.gpu
 
 
-def test_record_pack_and_rccl_gather_world1():
+@pytest.mark.parametrize("root", [0, None])
+def test_record_pack_and_rccl_gather_world1(root):
     import torch
     from importlib import import_module
     import psl_slam_amd as P
@@ -32,7 +34,8 @@ def test_record_pack_and_rccl_gather_world1():
         pipe.step(d_gray.data_ptr(), d_depth.data_ptr())
         if gat is None:
             layout = pipe.record_layout(mg)
-            gat = mg.RecordGather(pipe.ctx, layout, B, 0, 1, dev, lambda uid: uid)
+            gat = mg.RecordGather(pipe.ctx, layout, B, 0, 1, dev, lambda uid, ok: (uid, ok), root=root, recv_slots=1 if root is not None else 2)
+            assert gat.ranks_seen() == [0]
         k = gat.submit(pipe.record_sources(mg))
     rec = gat.result(k).cpu().numpy()
     torch.cuda.synchronize(dev)
@@ -56,3 +59,31 @@ def test_record_pack_and_rccl_gather_world1():
             ref = BP.oracle_frame(((f - 1) % B, gray[(f - 1) % B]), (f, gray[f]), depth[f], f, w, h, True, pipe.cam, cache=cache)
             BP.compare_frame(r, ref, f"frame {f}: ")
     gat.close()
+
+
+def test_record_pack_short_match_rows_read_no_match():
+    """A caller whose match buffers hold fewer rows than the record's capacity (match_stride < kp_cap): the rows beyond read -1
+    ("no match"), as the header documents and the numpy packer does - not 0 = "matched to keypoint 0"."""
+    import torch
+    import ctypes as C
+    from importlib import import_module
+    import psl_slam_amd as P
+    mg = import_module("psl_slam_amd.multigpu")
+    dev = torch.device("cuda", 0)
+    ctx = P.default_context()
+    layout = mg.RecordLayout(64, 16, 0, 0)
+    F = 3
+    match = torch.arange(F * 40, dtype=torch.int32, device=dev).reshape(F, 40)
+    lmatch = torch.arange(F * 10, dtype=torch.int32, device=dev).reshape(F, 10) + 1000
+    S = mg.RecordSources()
+    S.d_match, S.match_stride = match.data_ptr(), 40
+    S.d_lmatch, S.lmatch_stride = lmatch.data_ptr(), 10
+    rec = torch.empty((F, layout.bytes), dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize(dev)
+    P._check(P.lib().pslfe_record_pack_device(ctx._h, C.byref(layout.caps), C.byref(S), C.c_int(F), C.c_void_p(rec.data_ptr())), "pslfe_record_pack_device")
+    ctx.synchronize()
+    r = rec.cpu().numpy()
+    for f in range(F):
+        u = layout.unpack(r[f])
+        assert np.array_equal(u["match"][:40], np.arange(f * 40, f * 40 + 40)) and (u["match"][40:] == -1).all() and len(u["match"]) == 64
+        assert np.array_equal(u["lmatch"][:10], np.arange(f * 10, f * 10 + 10) + 1000) and (u["lmatch"][10:] == -1).all()

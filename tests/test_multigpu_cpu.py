@@ -122,3 +122,67 @@ def test_result_gather_gloo_world2_real_records():
     assert res[0][3].shape == single.shape and np.array_equal(res[0][3], single)
     u = layout.unpack(res[0][3][5])
     assert u["n_kp"] > 300 and u["n_match"] > 100
+
+
+# ---- bench.py's own launcher (python bench.py --gpus N without torchrun) and the torchrun launch, rehearsed with gloo -------------
+def _last_json(text):
+    import json
+    for line in reversed(text.splitlines()):
+        if line.startswith("{"):
+            return json.loads(line)
+    raise AssertionError("no JSON line in:\n" + text)
+
+
+def _clean_env():
+    return {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "PSLFE_BENCH_LAUNCHER")}
+
+
+def test_bench_spawns_its_own_ranks_gloo_rehearsal():
+    """python bench.py --gpus 2 with no launcher: two rank processes, rendezvous on 127.0.0.1, the collective agreement, the gather to
+    rank 0, ONE JSON line relayed from rank 0, exit code 0."""
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launcher-selftest"], capture_output=True, text=True,
+                       env=_clean_env(), timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = _last_json(r.stdout)
+    assert j["launcher_selftest"] and j["n_gpus"] == 2 and j["ranks_seen"] == [0, 1] and j["gather_ok"] and j["rccl_gather_agreed"]
+    assert j["launcher"] == "self"
+    assert sum(1 for line in r.stdout.splitlines() if line.startswith("{")) == 1
+
+
+def test_bench_gather_choice_is_collective():
+    """One rank that cannot create its communicator makes EVERY rank take the fallback (all_reduce MIN), and the run still completes."""
+    import subprocess
+    env = dict(_clean_env(), PSLFE_SELFTEST_FAIL_RANK="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launcher-selftest"], capture_output=True, text=True,
+                       env=env, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = _last_json(r.stdout)
+    assert j["rccl_gather_agreed"] is False and j["gather_ok"] and j["ranks_seen"] == [0, 1]
+
+
+def test_bench_under_torchrun_gloo_rehearsal():
+    """The launch the driver documents: python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2."""
+    import subprocess
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launcher-selftest"],
+                       capture_output=True, text=True, env=_clean_env(), timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = _last_json(r.stdout)
+    assert j["ranks_seen"] == [0, 1] and j["gather_ok"] and j["launcher"] == "external"
+
+
+def test_bench_multi_gpu_without_devices_fails_with_the_librarys_message():
+    """No GPU: both rank processes reach pslfe_ctx_create's PSLFE_E_NODEVICE and the launcher exits non-zero with that message
+    (not an AssertionError, not a hang)."""
+    import subprocess
+    import ctypes as C
+    import psl_slam_amd as P
+    h = C.c_void_p()
+    if P.lib().pslfe_ctx_create(C.c_int(0), C.byref(h)) == 0:
+        P.lib().pslfe_ctx_destroy(h)
+        pytest.skip("a GPU is present")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, env=_clean_env(), timeout=300)
+    assert r.returncode != 0
+    assert r.stderr.count("this library has no CPU fallback") == 2 and "rank 0" in r.stderr and "rank 1" in r.stderr
+    assert "AssertionError" not in r.stderr and not r.stdout.strip()

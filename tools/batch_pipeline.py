@@ -72,9 +72,12 @@ class BatchPipeline:
     def contexts(self):
         return [self.ctx] if self.ctx_l is self.ctx else [self.ctx, self.ctx_l]
 
-    def step(self, d_gray, d_depth=None):
-        """d_gray: device address of [B][h][w] u8, d_depth: [B][h][w] f32 (lines).  Asynchronous."""
-        P, B, w, h = self.P, self.B, self.w, self.h
+    def step(self, d_gray, d_depth=None, nframes=None):
+        """d_gray: device address of [B][h][w] u8, d_depth: [B][h][w] f32 (lines).  Asynchronous.  nframes <= B: only the first
+        nframes frames of the batch (frame 0's predecessor is then frame nframes-1)."""
+        P, w, h = self.P, self.w, self.h
+        B = self.B if nframes is None else int(nframes)
+        assert 1 <= B <= self.B
         self.orb.extract_batch_device(d_gray, B, w, h, w, w * h)
         k, d, c, _ = self.orb.results_device()
         self.grid.set_from_orb(self.orb, self.bounds)

@@ -6,7 +6,10 @@ repo=$GRAFT_REPO_ROOT
 out=$repo/gpurun_out/$1; shift
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $out/trace -o r --output-format csv -- python3 $repo/bench.py "$@" > $out/trace_bench.json 2> $out/trace.err
+# the input frames are generated (worker pool) and cached by an UNPROFILED run; under the profiler bench.py starts no process at all
+# (no pool, no CPU baseline, no device probe): the preload has initialised the GPU before the program starts
+python3 $repo/bench.py "$@" --prepare-inputs
+rocprofv3 --kernel-trace --stats -d $out/trace -o r --output-format csv -- python3 $repo/bench.py "$@" --no-cpu-baseline > $out/trace_bench.json 2> $out/trace.err
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $out/fetch -o r --output-format csv -- python3 $repo/bench.py "$@" --no-cpu-baseline > $out/fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $out/write -o r --output-format csv -- python3 $repo/bench.py "$@" --no-cpu-baseline > $out/write.log 2>&1
 if [ -x $repo/tools/pmc_calib/pmc_calib ]; then
