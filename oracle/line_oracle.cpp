@@ -863,6 +863,13 @@ double pso_lsd_nfa(int n, int k, double p, int W, int H) {
     l.LOG_NT = 5 * (std::log10(double(W)) + std::log10(double(H))) / 2 + std::log10(11.0);
     return l.nfa(n, k, p);
 }
+// the same with log(NT) given, and log_gamma alone: compared with the reference tree's twin (ED_Lib/NFA.cpp) in tests/test_oracle_ref_cpu.py
+double pso_lsd_nfa_lognt(int n, int k, double p, double logNT) {
+    Lsd l;
+    l.LOG_NT = logNT;
+    return l.nfa(n, k, p);
+}
+double pso_lsd_log_gamma(double x) { return Lsd::log_gamma(x); }
 // rectangles that reach rect_improve (12 doubles each: x1 y1 x2 y2 width x y theta dx dy prec p); returns their number
 int pso_lsd_rects(const uint8_t* gray, int w, int h, int stride, double* rects, int cap) {
     Lsd lsd;

@@ -138,3 +138,28 @@ def test_lsd_refine_adv_rejects_a_subset_and_is_insensitive_to_the_math_library(
             j += 1
         assert j < len(std), "an ADV segment that is not one of the STD rectangles, in order"
         j += 1
+
+
+def test_nfa_decisions_do_not_flip_between_libm_and_the_restated_math_over_many_frames():
+    """The device evaluates fdlibm-style log / exp / log10 (<= 1 - 2 ulp from glibc, not bit-identical): a near-tie in `log_nfa > 0` or
+    `v > log_nfa` could flip an accept / reject against the reference's libm.  Counted instead of assumed: 240 synthetic frames,
+    every segment list compared between pso_set_nfa_math(0) (host libm, what the reference calls) and (1) (what the device runs)."""
+    flips = frames = segments = 0
+    try:
+        for style, seeds in (("struct", range(100, 130)), ("desk", range(200, 230))):
+            for seed in seeds:
+                sc = sf.Scene(320, 240, style, seed)
+                for t in range(4):
+                    img = sc.gray(7 * t)
+                    oracle_lib.set_nfa_math(0)
+                    a = oracle_lib.lsd_detect(img)
+                    oracle_lib.set_nfa_math(1)
+                    b = oracle_lib.lsd_detect(img)
+                    frames += 1
+                    segments += len(a)
+                    if a.tobytes() != b.tobytes():
+                        flips += 1
+    finally:
+        oracle_lib.set_nfa_math(0)
+    assert frames == 240 and segments > 5000, (frames, segments)
+    assert flips == 0, f"{flips} of {frames} frames changed their segment list with the restated math"
