@@ -11,6 +11,8 @@
 #define PSLFE_HPP
 
 #include <cstdint>
+#include <cstring>
+#include <deque>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -301,8 +303,8 @@ public:
         std::vector<double> cross3d;   // CrossPoint_3D, p x 3
         std::vector<double> cross2d;   // CrossPoint_2D, p x 2
     };
-    FrameGlue(Context& ctx, int maxLines = 1024, int maxFans = 4096) : maxFans_(maxFans) {
-        check(pslfe_glue_create(ctx.get(), maxLines, maxFans, 1, &h_), "pslfe_glue_create");
+    FrameGlue(Context& ctx, int maxLines = 1024, int maxFans = 4096, int maxBatch = 1) : maxFans_(maxFans) {
+        check(pslfe_glue_create(ctx.get(), maxLines, maxFans, maxBatch, &h_), "pslfe_glue_create");
     }
     ~FrameGlue() { pslfe_glue_destroy(h_); }
     FrameGlue(const FrameGlue&) = delete;
@@ -310,15 +312,20 @@ public:
     // fans: the n x 4 matrix of CPartiallyRecoverConnectivity; seed: srand(seed) of the frame (convention H7)
     Result run(const std::vector<PslKeyLine>& keylines, const std::vector<float>& fans, const float* depth, int cols, int rows, int strideFloats,
                const PslCamera& cam, uint32_t seed) {
-        const int n = (int)keylines.size(), nf = (int)fans.size() / 4, cap = maxFans_;
+        const int n = (int)keylines.size(), nf = (int)fans.size() / 4;
         check(pslfe_glue_run(h_, keylines.data(), n, fans.data(), nf, depth, cols, rows, strideFloats, &cam, seed), "pslfe_glue_run");
+        return fetch(0, n);
+    }
+    // results of frame `frame` of the last run / pslfe_glue_run_batch_device; n = that frame's keyline count
+    Result fetch(int frame, int n) {
+        const int cap = maxFans_;
         Result r;
         r.lines3d.resize((size_t)n * 6); r.lineEq.resize((size_t)n * 3);
         r.pair.resize((size_t)cap * 2); r.xy.resize((size_t)cap * 2); r.cross.resize((size_t)cap * 3); r.le_l.resize((size_t)cap * 6);
         r.planes.resize((size_t)cap * 4); r.normals.resize((size_t)cap * 3); r.lineNo.resize((size_t)cap * 2);
         r.cross3d.resize((size_t)cap * 3); r.cross2d.resize((size_t)cap * 2);
         int k = 0, p = 0;
-        check(pslfe_glue_fetch(h_, 0, n, r.lines3d.data(), r.lineEq.data(), r.pair.data(), r.xy.data(), r.cross.data(), r.le_l.data(), cap, &k,
+        check(pslfe_glue_fetch(h_, frame, n, r.lines3d.data(), r.lineEq.data(), r.pair.data(), r.xy.data(), r.cross.data(), r.le_l.data(), cap, &k,
                                r.planes.data(), r.normals.data(), r.lineNo.data(), r.cross3d.data(), r.cross2d.data(), cap, &p),
               "pslfe_glue_fetch");
         r.pair.resize((size_t)k * 2); r.xy.resize((size_t)k * 2); r.cross.resize((size_t)k * 3); r.le_l.resize((size_t)k * 6);
@@ -326,9 +333,158 @@ public:
         r.cross3d.resize((size_t)p * 3); r.cross2d.resize((size_t)p * 2);
         return r;
     }
+    pslfe_glue* get() const { return h_; }
 private:
     pslfe_glue* h_ = nullptr;
     int maxFans_;
+};
+
+// == Look-ahead extraction for the Tracking loop.  The reference's caller is a sequential loop over the frames of a recording
+//    (Examples/RGB-D/rgbd_tum.cc:88-130) that constructs one Frame per image (src/Tracking.cc:240 -> src/Frame.cc:133-208); nothing the
+//    Frame constructor computes depends on the pose of an earlier frame, so the extraction of frames t+1 .. t+K can run in ONE batched
+//    launch while frame t is being tracked.  push() stages a frame (gray + CV_32F depth, copied to HBM); pop() hands out the oldest
+//    staged frame's Frame members - when none is ready, the staged frames (up to `lookahead`) go through
+//        pslfe_orb_extract_batch_device, pslfe_line_extract_batch_device, pslfe_line_pair_batch_device,
+//        pslfe_glue_run_batch_device, pslfe_frame_set_from_orb_rgbd, pslfe_record_pack_device
+//    in one go and the packed per-frame records come back in one copy.  Frame k of a batch sits in slot k of grid() until the NEXT
+//    batch is launched, i.e. until the pop() after the batch's last frame: call the matchers for a frame before popping the next one
+//    (as a Tracking thread does).  isLineGood's rand() stream is seeded with 1 + the frame's running index (convention H7), so the
+//    results are those of the one-frame-at-a-time path, bit for bit, whatever the look-ahead.
+//    A live camera pays K - 1 frames of latency for this; a recording pays nothing.
+class FramePrefetcher {
+public:
+    struct Frame {   // the members of ORB_SLAM2::Frame this path fills
+        uint64_t index = 0;   // running index of the frame (push order)
+        int slot = 0;         // its slot in grid(): SearchByProjection(prefetcher.grid(), frame.slot, ...)
+        std::vector<PslKeyPoint> mvKeys, mvKeysUn;
+        std::vector<uint8_t> mDescriptors;
+        std::vector<float> mvDepth, mvuRight;
+        std::vector<PslKeyLine> mvKeylinesUn;
+        std::vector<uint8_t> mLdesc;
+        std::vector<double> mvKeyLineFunctions;
+        std::vector<float> fans;
+        FrameGlue::Result glue;
+    };
+
+    FramePrefetcher(Context& ctx, int cols, int rows, int lookahead, int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST,
+                    int nLSDFeature, const PslCamera& cam, float pairRadius = 20.0f, float fanThr = 0.78539816339744830962f)
+        : ctx_(ctx), w_(cols), h_(rows), K_(lookahead < 1 ? 1 : lookahead), nlines_(nLSDFeature), cam_(cam), radius_(pairRadius), fanThr_(fanThr),
+          orb_(ctx, nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, K_), lsd_(ctx, 1, 1.2f, (unsigned)nLSDFeature, 0.0, K_),
+          kpCap_(pslfe_orb_max_keypoints(orb_.get(), cols, rows)), grid_(ctx, kpCap_ > 0 ? kpCap_ : 1, K_) {
+        if (kpCap_ < 0) throw Error(kpCap_, "pslfe_orb_max_keypoints");
+        check(pslfe_device_alloc(ctx.get(), (size_t)K_ * w_ * h_, &d_gray_), "pslfe_device_alloc");
+        check(pslfe_device_alloc(ctx.get(), (size_t)K_ * w_ * h_ * sizeof(float), &d_depth_), "pslfe_device_alloc");
+        caps_.kp_cap = kpCap_; caps_.kl_cap = nLSDFeature; caps_.fan_cap = 4096; caps_.plane_cap = 0;
+        check(pslfe_record_layout(&caps_, &lay_), "pslfe_record_layout");
+        check(pslfe_device_alloc(ctx.get(), (size_t)K_ * lay_.bytes, &d_rec_), "pslfe_device_alloc");
+        rec_.resize((size_t)K_ * lay_.bytes);
+    }
+    ~FramePrefetcher() {
+        pslfe_device_free(ctx_.get(), d_gray_); pslfe_device_free(ctx_.get(), d_depth_); pslfe_device_free(ctx_.get(), d_rec_);
+        delete glue_;
+    }
+    FramePrefetcher(const FramePrefetcher&) = delete;
+    FramePrefetcher& operator=(const FramePrefetcher&) = delete;
+
+    int lookahead() const { return K_; }
+    size_t staged() const { return (size_t)staged_; }                 // pushed, not yet extracted
+    size_t ready() const { return (size_t)(batch_n_ - batch_next_); }   // extracted, not yet popped
+    FrameGrid& grid() { return grid_; }
+    ORBextractor& orbExtractor() { return orb_; }
+    LINEextractor& lineExtractor() { return lsd_; }
+
+    // Stages one frame: gray 8UC1 (`grayStep` bytes per row), depth CV_32F in metres (`depthStep` floats per row).  At most `lookahead`
+    // frames can be staged: returns false (and stages nothing) when the staging area is full or frames of the previous batch are
+    // still waiting to be popped beyond what the slots hold.
+    bool push(const uint8_t* gray, int grayStep, const float* depth, int depthStep) {
+        if (!gray || !depth || staged_ >= K_ || ready() > 0) return false;
+        uint8_t* dg = static_cast<uint8_t*>(d_gray_) + (size_t)staged_ * w_ * h_;
+        float* dd = static_cast<float*>(d_depth_) + (size_t)staged_ * w_ * h_;
+        if (grayStep != w_) {   // rows with padding: packed on the host first, one copy either way
+            tmp8_.resize((size_t)w_ * h_);
+            for (int y = 0; y < h_; ++y) memcpy(tmp8_.data() + (size_t)y * w_, gray + (size_t)y * grayStep, (size_t)w_);
+            gray = tmp8_.data();
+        }
+        if (depthStep != w_) {
+            tmp32_.resize((size_t)w_ * h_);
+            for (int y = 0; y < h_; ++y) memcpy(tmp32_.data() + (size_t)y * w_, depth + (size_t)y * depthStep, (size_t)w_ * sizeof(float));
+            depth = tmp32_.data();
+        }
+        check(pslfe_device_upload(ctx_.get(), dg, gray, (size_t)w_ * h_), "pslfe_device_upload");
+        check(pslfe_device_upload(ctx_.get(), dd, depth, (size_t)w_ * h_ * sizeof(float)), "pslfe_device_upload");
+        ++staged_;
+        return true;
+    }
+
+    // Extracts every staged frame now (one batched launch).  pop() calls it when nothing is ready.
+    void flush() {
+        if (staged_ == 0 || ready() > 0) return;
+        const int F = staged_;
+        const uint8_t* dg = static_cast<const uint8_t*>(d_gray_);
+        const float* dd = static_cast<const float*>(d_depth_);
+        check(pslfe_orb_extract_batch_device(orb_.get(), dg, F, w_, h_, w_, (size_t)w_ * h_), "pslfe_orb_extract_batch_device");       // ExtractORB
+        check(pslfe_line_extract_batch_device(lsd_.get(), dg, F, w_, h_, w_, (size_t)w_ * h_), "pslfe_line_extract_batch_device");   // ExtractLSD: extractor
+        check(pslfe_line_pair_batch_device(lsd_.get(), radius_, fanThr_), "pslfe_line_pair_batch_device");                              // src/Frame.cc:505
+        PslRecordSources S;
+        memset(&S, 0, sizeof(S));
+        check(pslfe_orb_results_device(orb_.get(), &S.d_kps, &S.d_desc, &S.d_kp_counts, &S.kp_stride), "pslfe_orb_results_device");
+        check(pslfe_line_results_device(lsd_.get(), &S.d_kls, &S.d_ldesc, &S.d_lineEq, &S.d_kl_counts, &S.kl_stride), "pslfe_line_results_device");
+        check(pslfe_line_fans_device(lsd_.get(), &S.d_fans, &S.d_fan_counts, &S.fan_stride), "pslfe_line_fans_device");
+        if (!glue_) glue_ = new FrameGlue(ctx_, S.kl_stride, S.fan_stride, K_);
+        check(pslfe_glue_run_batch_device(glue_->get(), F, S.d_kls, S.kl_stride, S.d_kl_counts, S.d_fans, S.fan_stride, S.d_fan_counts, dd, w_, h_, &cam_,
+                                          (uint32_t)(1u + next_index_)), "pslfe_glue_run_batch_device");                               // isLineGood, fans, planes
+        check(pslfe_frame_set_from_orb_rgbd(grid_.get(), orb_.get(), dd, w_, h_, &cam_), "pslfe_frame_set_from_orb_rgbd");            // Undistort .. AssignFeaturesToGrid
+        check(pslfe_record_pack_device(ctx_.get(), &caps_, &S, F, d_rec_), "pslfe_record_pack_device");
+        check(pslfe_device_download(ctx_.get(), rec_.data(), d_rec_, (size_t)F * lay_.bytes), "pslfe_device_download");
+        batch_n_ = F; batch_next_ = 0; batch_index0_ = next_index_;
+        next_index_ += (uint64_t)F;
+        staged_ = 0;
+    }
+
+    // The oldest frame not handed out yet; false when nothing is staged or ready.
+    bool pop(Frame& out) {
+        if (ready() == 0) flush();
+        if (ready() == 0) return false;
+        const int k = batch_next_++;
+        const uint8_t* r = rec_.data() + (size_t)k * lay_.bytes;
+        int32_t hd[8];
+        memcpy(hd, r, sizeof(hd));
+        const int nkp = hd[0], nkl = hd[2], nfan = hd[4];
+        if ((hd[6] & 7) != 0) throw Error(PSLFE_E_CAPACITY, "FramePrefetcher: a frame's results exceed the record capacities");
+        out.index = batch_index0_ + (uint64_t)k; out.slot = k;
+        out.mvKeys.resize(nkp); out.mDescriptors.resize((size_t)nkp * 32);
+        out.mvKeylinesUn.resize(nkl); out.mLdesc.resize((size_t)nkl * 32); out.mvKeyLineFunctions.resize((size_t)nkl * 3);
+        out.fans.resize((size_t)nfan * 4);
+        if (nkp) { memcpy(out.mvKeys.data(), r + lay_.off_kps, (size_t)nkp * sizeof(PslKeyPoint)); memcpy(out.mDescriptors.data(), r + lay_.off_desc, (size_t)nkp * 32); }
+        if (nkl) {
+            memcpy(out.mvKeylinesUn.data(), r + lay_.off_kls, (size_t)nkl * sizeof(PslKeyLine));
+            memcpy(out.mLdesc.data(), r + lay_.off_ldesc, (size_t)nkl * 32);
+            memcpy(out.mvKeyLineFunctions.data(), r + lay_.off_lineEq, (size_t)nkl * 3 * sizeof(double));
+        }
+        if (nfan) memcpy(out.fans.data(), r + lay_.off_fans, (size_t)nfan * 4 * sizeof(float));
+        out.glue = glue_->fetch(k, nkl);                                          // mvLines3D, crossings, mvPlanes ...
+        if (nkp) grid_.fetch(k, out.mvKeysUn, out.mvDepth, out.mvuRight, kpCap_);   // mvKeysUn, mvDepth, mvuRight
+        else { out.mvKeysUn.clear(); out.mvDepth.clear(); out.mvuRight.clear(); }
+        return true;
+    }
+
+private:
+    Context& ctx_;
+    int w_, h_, K_, nlines_;
+    PslCamera cam_;
+    float radius_, fanThr_;
+    ORBextractor orb_;
+    LINEextractor lsd_;
+    int kpCap_;
+    FrameGrid grid_;
+    FrameGlue* glue_ = nullptr;   // created after the first batch: its row stride is the line extractor's (pslfe_line_results_device)
+    void* d_gray_ = nullptr; void* d_depth_ = nullptr; void* d_rec_ = nullptr;
+    PslRecordCaps caps_;
+    PslRecordLayout lay_;
+    std::vector<uint8_t> rec_, tmp8_;
+    std::vector<float> tmp32_;
+    int staged_ = 0, batch_n_ = 0, batch_next_ = 0;
+    uint64_t next_index_ = 0, batch_index0_ = 0;
 };
 
 // DBoW2 ORBVocabulary as far as Frame::ComputeBoW needs it (src/Frame.cc:1053-1060): the tree as flat arrays, transform on the device.

@@ -13,7 +13,11 @@
 // was seen at (the synthetic stream drifts by <= 2 px per frame), the "map" of planes is the last frame's planes.
 // Per-frame wall time is what the reference itself reports (Examples/RGB-D/rgbd_tum.cc:103-119).
 //
-// usage: dropin_main <frames.bin> <nfeatures> <nlines> <warmup> [results.bin]
+// With a look-ahead K > 1 the Frame members come from pslfe::FramePrefetcher instead: the "reader" pushes up to K frames ahead
+// (Examples/RGB-D/rgbd_tum.cc:88-93 reads them from disk), their extraction runs as ONE batched launch, and every frame is then tracked
+// as before.  Results are those of K = 1 bit for bit.
+//
+// usage: dropin_main <frames.bin> <nfeatures> <nlines> <warmup> [results.bin | -] [lookahead]
 //   frames.bin : int32 magic 0x50534C46, w, h, n; n gray frames (w*h u8); n depth frames (w*h f32, metres)
 //   results.bin: per frame the outputs a parity test compares with the oracle (see dump()).
 #include <algorithm>
@@ -31,16 +35,7 @@
 using Clock = std::chrono::steady_clock;
 static double ms_since(Clock::time_point t0) { return std::chrono::duration<double, std::milli>(Clock::now() - t0).count(); }
 
-struct FrameData {  // the members of ORB_SLAM2::Frame this path fills
-    std::vector<PslKeyPoint> mvKeys, mvKeysUn;
-    std::vector<uint8_t> mDescriptors;
-    std::vector<float> mvDepth, mvuRight;
-    std::vector<PslKeyLine> mvKeylinesUn;
-    std::vector<uint8_t> mLdesc;
-    std::vector<double> mvKeyLineFunctions;
-    std::vector<float> fans;
-    pslfe::FrameGlue::Result glue;
-};
+typedef pslfe::FramePrefetcher::Frame FrameData;  // the members of ORB_SLAM2::Frame this path fills
 
 template <class T> static void put(FILE* f, const std::vector<T>& v) {
     const int64_t n = (int64_t)v.size();
@@ -62,23 +57,27 @@ int main(int argc, char** argv) {
         fprintf(stderr, "short frames file\n"); return 2;
     }
     fclose(fi);
-    FILE* fo = argc > 5 ? fopen(argv[5], "wb") : nullptr;
+    FILE* fo = (argc > 5 && strcmp(argv[5], "-") != 0) ? fopen(argv[5], "wb") : nullptr;
+    const int lookahead = argc > 6 ? std::max(1, atoi(argv[6])) : 1;
 
     try {
         pslfe::Context ctx(0);
-        pslfe::ORBextractor orb(ctx, nfeatures, 1.2f, 8, 20, 7);               // src/Tracking.cc:120
-        pslfe::LINEextractor lsd(ctx, 1, 1.2f, (unsigned)nlines, 0.0);         // src/Tracking.cc:127
-        const int cap = pslfe_orb_max_keypoints(orb.get(), w, h);
-        pslfe::FrameGrid grid(ctx, cap, 2);
-        pslfe::FrameGlue glue(ctx, 2048, 4096);
-        pslfe::ORBmatcher matcher(0.9f, true);
-        pslfe::LSDmatcher lmatcher(ctx);
-        const std::vector<float> scale = orb.GetScaleFactors();
         // Examples/RGB-D/TUM3.yaml scaled with the image width (zero distortion, as every RGB-D YAML of the reference)
         const float s = (float)w / 640.0f;
         PslCamera cam = {535.4f * s, 539.2f * s, 320.1f * s, 247.6f * s, 0, 0, 0, 0, 0, 40.0f * s};
+        pslfe::ORBextractor orb(ctx, nfeatures, 1.2f, 8, 20, 7);               // src/Tracking.cc:120
+        pslfe::LINEextractor lsd(ctx, 1, 1.2f, (unsigned)nlines, 0.0);         // src/Tracking.cc:127
+        const int cap = pslfe_orb_max_keypoints(orb.get(), w, h);
+        pslfe::FrameGrid grid1(ctx, cap, 2);
+        pslfe::FrameGlue glue(ctx, 2048, 4096);
+        pslfe::FramePrefetcher* pf = lookahead > 1 ? new pslfe::FramePrefetcher(ctx, w, h, lookahead, nfeatures, 1.2f, 8, 20, 7, nlines, cam) : nullptr;
+        pslfe::FrameGrid& grid = pf ? pf->grid() : grid1;
+        pslfe::ORBmatcher matcher(0.9f, true);
+        pslfe::LSDmatcher lmatcher(ctx);
+        const std::vector<float> scale = orb.GetScaleFactors();
         float bounds[4];
         grid.imageBounds(cam, w, h, bounds);  // ComputeImageBounds, first frame only (src/Frame.cc:158-174)
+        int next_push = 0;
 
         std::map<std::string, std::vector<double>> T;  // per-call times of the timed frames
         std::vector<double> frame_ms, track_ms;
@@ -102,6 +101,15 @@ int main(int argc, char** argv) {
             // ---------------- Frame::Frame ----------------
             const auto tf = Clock::now();
             auto t0 = tf;
+            int slot = t & 1;
+            if (pf) {   // look-ahead: the reader is up to K frames ahead of the tracker; the Frame members come out of the prefetcher
+                if (pf->ready() == 0)
+                    while (next_push < n && pf->push(gray.data() + (size_t)next_push * w * h, w, depth.data() + (size_t)next_push * w * h, w)) ++next_push;
+                lap("FramePrefetcher push (H2D)", t0);
+                if (!pf->pop(cur)) { fprintf(stderr, "dropin_main: the prefetcher ran dry at frame %d\n", t); return 1; }
+                slot = cur.slot;
+                lap("FramePrefetcher pop", t0);
+            } else {
             orb(img, w, h, w, cur.mvKeys, cur.mDescriptors);                                   // ExtractORB
             lap("ORBextractor()", t0);
             lsd(img, w, h, w, cur.mvKeylinesUn, cur.mLdesc, cur.mvKeyLineFunctions);           // ExtractLSD: extractor
@@ -120,6 +128,7 @@ int main(int argc, char** argv) {
                 grid.fetch(t & 1, cur.mvKeysUn, cur.mvDepth, cur.mvuRight, cap);
             }
             lap("Undistort+StereoFromRGBD+Grid", t0);
+            }
             const double fms = ms_since(tf);
             // ---------------- Tracking::TrackWithMotionModel ----------------
             const auto tt = Clock::now();
@@ -140,7 +149,7 @@ int main(int argc, char** argv) {
                         q[i].angle = k.angle; q[i].blocks = 1;
                     }
                     assigned.assign(cur.mvKeys.size(), -1);
-                    return matcher.SearchByProjection(grid, t & 1, q, last.mDescriptors, nullptr, match, &assigned);
+                    return matcher.SearchByProjection(grid, slot, q, last.mDescriptors, nullptr, match, &assigned);
                 };
                 nmatches = project(15);
                 lap("SearchByProjection(cur,last)", t0);
@@ -189,13 +198,13 @@ int main(int argc, char** argv) {
         for (size_t i = 0; i < m; ++i) total[i] = frame_ms[i] + track_ms[i];
         double med, mean, p95, fmed, fmean, fp95, tmed, tmean, tp95;
         stats(total, &med, &mean, &p95); stats(frame_ms, &fmed, &fmean, &fp95); stats(track_ms, &tmed, &tmean, &tp95);
-        printf("{\"frames_timed\": %zu, \"w\": %d, \"h\": %d, \"nfeatures\": %d, \"nlines\": %d, "
+        printf("{\"frames_timed\": %zu, \"lookahead\": %d, \"w\": %d, \"h\": %d, \"nfeatures\": %d, \"nlines\": %d, "
                "\"ms_per_frame\": {\"median\": %.4f, \"mean\": %.4f, \"p95\": %.4f}, "
                "\"frame_ctor_ms\": {\"median\": %.4f, \"mean\": %.4f, \"p95\": %.4f}, "
                "\"track_ms\": {\"median\": %.4f, \"mean\": %.4f, \"p95\": %.4f}, "
                "\"mean_keypoints\": %.1f, \"mean_keylines\": %.1f, \"mean_fans\": %.1f, \"mean_planes\": %.1f, \"mean_matches\": %.1f, "
                "\"mean_line_matches\": %.1f, \"retries\": %ld, \"calls_ms_mean\": {",
-               m, w, h, nfeatures, nlines, med, mean, p95, fmed, fmean, fp95, tmed, tmean, tp95, (double)sum_kp / m, (double)sum_kl / m,
+               m, lookahead, w, h, nfeatures, nlines, med, mean, p95, fmed, fmean, fp95, tmed, tmean, tp95, (double)sum_kp / m, (double)sum_kl / m,
                (double)sum_fans / m, (double)sum_planes / m, (double)sum_nm / m, (double)sum_lm / m, retries);
         bool first = true;
         for (auto& kv : T) {
@@ -220,6 +229,7 @@ int main(int argc, char** argv) {
             printf("}");
         }
         printf("}\n");
+        delete pf;
     } catch (const std::exception& e) {
         fprintf(stderr, "dropin_main: %s\n", e.what());
         return 1;

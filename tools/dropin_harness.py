@@ -39,11 +39,12 @@ def write_frames(path, gray, depth):
         np.ascontiguousarray(depth, np.float32).tofile(f)
 
 
-def run(frames_path, nfeatures, nlines, warmup, results_path=None, stages=False, timeout=600):
+def run(frames_path, nfeatures, nlines, warmup, results_path=None, stages=False, timeout=600, lookahead=1):
+    """lookahead K > 1: the Frame members come from pslfe::FramePrefetcher (K frames extracted per batched launch)."""
     env = dict(os.environ)
     if stages:
         env["PSLFE_DROPIN_STAGES"] = "1"
-    cmd = [build(), frames_path, str(nfeatures), str(nlines), str(warmup)] + ([results_path] if results_path else [])
+    cmd = [build(), frames_path, str(nfeatures), str(nlines), str(warmup), results_path or "-", str(int(lookahead))]
     p = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=timeout)
     if p.returncode != 0:
         raise RuntimeError(f"dropin_main failed ({p.returncode}): {p.stderr[-2000:]}")
