@@ -409,7 +409,7 @@ __device__ __forceinline__ double psl_lsd_density(int reg_size, const LsdRect& r
 // Wave-uniform logic runs on the scalar unit (masks, counters) or redundantly in all lanes (the float sums).
 // ---------------------------------------------------------------------------------------------
 #ifndef PSL_LSD_RING
-#define PSL_LSD_RING 1024   // queue entries kept in LDS (a power of two >= 128).  A frontier that lags more than half of this behind the queue's end
+#define PSL_LSD_RING 512    // queue entries kept in LDS (a power of two >= 128; 1024 until round 3: 512 x 4 B lets 32 waves per CU fit the 160 KB of LDS).  A frontier that lags more than half of this behind the queue's end
                             // does not occur on 8-bit images (the gradient threshold of 5.2 grey levels per pixel limits a region to ~50 pixels along
                             // its gradient, hence the breadth-first frontier to ~100 entries): that path is exercised by building with
                             // -DPSL_LSD_RING=128 and running tests/test_line_gpu.py (its "band" image reaches a lag of 85)
@@ -870,8 +870,11 @@ __device__ __forceinline__ void psl_lsd_store_segment(const LineParams& P, doubl
 }
 
 #ifndef PSL_GROW_WAVES
-#define PSL_GROW_WAVES 6   // waves per SIMD: measured on 12288 frames (tools/occ_sweep.sh) 5: 60.5 ms, 6: 52.1 ms, 7: 53.4 ms (72 VGPRs, more spills);
-                           // without a bound the kernel takes 105 VGPRs (4 waves): 63.1 ms
+#define PSL_GROW_WAVES 8   // waves per SIMD.  Round 2 (1024-entry ring, 12288 struct frames, tools/occ_sweep.sh): 5: 60.5 ms, 6: 52.1 ms, 7: 53.4 ms - but 5.9 KB of
+                           // LDS per wave capped the CU at 27 waves, so 7 and 8 never ran.  Round 3, 512-entry ring (3.8 KB per wave, 32 waves per CU), 12288 frames of
+                           // the dense scene, A/B in one session (tools/ab_round3.sh, profiles/r03c_ab_waves.log): 6: 261.3 ms, 7: 246.3 ms, 8: 242.8 ms (64 VGPRs, 36
+                           // spilled to scratch, 133 SGPR spills: the kernel is bound by instruction issue, not by the waves in flight; -7 %).
+                           // Without a bound the kernel takes 105 VGPRs (4 waves): 63.1 ms on the struct scene
 #endif
 // HELPERS: launches of a few frames (one workgroup per XCD at most) run the chain on wave 0 and let HELPERS more waves of the same
 // workgroup - hence the same XCD's L2 - read one dword of every 64-byte piece of the frame's neighbour records, angles and `used` map

@@ -194,6 +194,85 @@ __device__ __forceinline__ void lsdn_count(const float* __restrict__ ang, int W,
     for (int j = 0; j < NP; ++j) alg[j] = lsdn_group_sum<GL>(al[j]);
 }
 
+// The five trial rectangles of a width-reduction / side-reduction phase of rect_improve() differ by quarter- and half-pixel steps:
+// their pixel scans cover nearly the same pixels, with the same theta and tolerance.  ONE pass over the union of their row spans:
+// a pixel's angle is loaded and tested for alignment once, and counted for every trial whose span of that row holds it (the spans
+// are rect_nfa's own, per trial: corners truncated to int, integer slopes - membership is not a function of the distance to the
+// axis).  total_pts needs no pixel at all: it is the sum of the span lengths.  The five geometries live in LDS as nine 32-bit
+// integers each (corner coordinates are a few hundred, slopes and row counts likewise: the closed form of a row's bounds stays
+// far inside 32 bits), written by lanes 0 - 4 of the group - lane t builds trial t - so that the scan itself runs in ~60
+// registers: with the geometries in registers the kernel took 122 and half the waves per SIMD, and was slower than five scans.
+struct LsdnGeomI { int ya, yb, lefty, righty, minx, fl, sl, fr, sr; };   // yb < ya: no in-image row; yb == -2: excluded by the width guard
+typedef __attribute__((address_space(3))) const int lds_cint;
+
+__device__ __forceinline__ void lsdn_row_span_i(lds_cint* g, int y, int W, int* xa, int* xb) {
+    const int ya = g[0], lefty = g[2], righty = g[3], minx = g[4];
+    const int n = y - ya;
+    int c1 = (y < lefty ? y : lefty) - ya; c1 = c1 < 0 ? 0 : c1;
+    int d1 = (y < righty ? y : righty) - ya; d1 = d1 < 0 ? 0 : d1;
+    const int L = minx + g[5] * c1 + g[6] * (n - c1);
+    const int R = minx + g[7] * d1 + g[8] * (n - d1);
+    *xa = L < 0 ? 0 : (L > W ? W : L);
+    *xb = R >= W ? W - 1 : (R < -1 ? -1 : R);
+}
+
+template <int GL>
+__device__ __forceinline__ void lsdn_count_trials(const float* __restrict__ ang, int W, lds_cint* geo, double theta, double prec, int lane, int* total, int* alg) {
+    const float theta_deg = (float)(theta * 57.295779513082320877), pdeg = (float)(prec * 57.295779513082320877);
+    auto aligned = [&](float a) -> bool {   // isAligned: f32 degrees first, the reference's f64 arithmetic inside the margin (see lsdn_count)
+        if (a == PSL_LSD_NOTDEF) return false;
+        float d = __builtin_fabsf(theta_deg - a);
+        const float d2 = __builtin_fabsf(d - 360.0f);
+        d = d > 270.0f ? d2 : d;
+        if (__builtin_fabsf(d - 270.0f) < 2e-3f || __builtin_fabsf(d - pdeg) < 2e-3f) return lsdg_fold(PSL_DMUL((double)a, PSL_DEG2RAD), theta) <= prec;
+        return d <= pdeg;
+    };
+    int ya = 0, yb = -1;   // union of the trials' in-image rows (empty: no trial has one)
+    bool any = false;
+#pragma unroll
+    for (int t = 0; t < 5; ++t) {
+        const int a = geo[9 * t], b = geo[9 * t + 1];
+        if (b >= a) {
+            ya = !any || a < ya ? a : ya;
+            yb = !any || b > yb ? b : yb;
+            any = true;
+        }
+    }
+    int tot[5], al[5];
+#pragma unroll
+    for (int t = 0; t < 5; ++t) { tot[t] = 0; al[t] = 0; }
+    const bool by_row = yb - ya + 1 >= GL;   // lane = row (four loads of the row in flight), or - few, long rows - row after row with the lanes sharing it
+    for (int y = by_row ? ya + lane : ya; y <= yb; y += by_row ? GL : 1) {
+        int xa[5], xb[5], ua = 0x7fffffff, ub = -1;
+#pragma unroll
+        for (int t = 0; t < 5; ++t) {
+            xa[t] = 1; xb[t] = 0;
+            if (y >= geo[9 * t] && y <= geo[9 * t + 1]) lsdn_row_span_i(geo + 9 * t, y, W, &xa[t], &xb[t]);
+            if (xb[t] >= xa[t]) {
+                if (by_row || lane == 0) tot[t] += xb[t] - xa[t] + 1;
+                ua = xa[t] < ua ? xa[t] : ua; ub = xb[t] > ub ? xb[t] : ub;
+            }
+        }
+        if (ub < ua) continue;   // no trial has a pixel in this row (ua is still the sentinel: never form an address from it)
+        const float* row = ang + y * W;
+        const int step = by_row ? 1 : GL;
+        for (int x = by_row ? ua : ua + lane; x <= ub; x += 4 * step) {
+            float a[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) a[u] = x + step * u <= ub ? row[x + step * u] : PSL_LSD_NOTDEF;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (aligned(a[u])) {
+#pragma unroll
+                    for (int t = 0; t < 5; ++t) al[t] += (x + step * u >= xa[t] && x + step * u <= xb[t]) ? 1 : 0;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 5; ++t) { total[t] = lsdn_group_sum<GL>(tot[t]); alg[t] = lsdn_group_sum<GL>(al[t]); }
+}
+
 // ---- nfa() ------------------------------------------------------------------------------------------------------------
 // pow(x, n) for the integer-valued arguments log_gamma sees: exact products where libm's pow is exact as well (x <= 15,
 // n <= 6); x^6 = (x^3)^2 with x^3 exact, i.e. one rounding - what a pow with < 1 ulp of error returns - for the Windschitl term
@@ -347,8 +426,9 @@ __device__ __forceinline__ void lsdn_load(const double* __restrict__ r, LsdnRect
 template <int PH>
 __global__ __launch_bounds__(256, 4) void k_lsd_nfa_count(LineParams P, const float* __restrict__ angdeg, double* __restrict__ rects,
                                                           const int* __restrict__ nrect, const uint8_t* __restrict__ keep, int2* __restrict__ counts) {
-    constexpr int TR = (PH >= 0 && PH <= 2) ? 5 : 1;   // scans per rectangle
+    constexpr int TR = 1;                               // scans per rectangle: the five trials of a phase share ONE pass (lsdn_count_trials / lsdn_count<5>)
     constexpr int GPB = 256 / PSL_NFA_GL;               // scans in flight per workgroup
+    __shared__ int s_geo[GPB * 45];                     // per scan group: five trial geometries (LsdnGeomI)
     const int frame = blockIdx.y, lane = threadIdx.x & (PSL_NFA_GL - 1);
     const int cnt = nrect[frame] < P.maxseg ? nrect[frame] : P.maxseg;
     const float* ang = angdeg + (size_t)frame * P.W * P.H;
@@ -381,19 +461,38 @@ __global__ __launch_bounds__(256, 4) void k_lsd_nfa_count(LineParams P, const fl
 #pragma unroll
                 for (int t = 0; t < 5; ++t) out[t] = make_int2(tot, kk[t]);
             }
-        } else {
-            bool valid = true;
-            if (PH >= 0) {               // trial j = j + 1 cumulative steps, each under the width guard (it only ever turns false)
-                for (int t = 0; t <= j; ++t) {
-                    if (!(PSL_DSUB(rec.width, 0.5) >= 0.5)) { valid = false; break; }
-                    lsdn_shrink(rec, PH);
+        } else if (PH >= 0) {            // trial t = t + 1 cumulative steps, each under the width guard (it only ever turns false)
+            int* geo = &s_geo[(threadIdx.x / PSL_NFA_GL) * 45];
+            if (lane < 5) {              // lane t builds trial t's geometry
+                LsdnRect r = rec;
+                bool valid = true;
+                for (int t = 0; t <= lane; ++t) {
+                    if (!(PSL_DSUB(r.width, 0.5) >= 0.5)) { valid = false; break; }
+                    lsdn_shrink(r, PH);
+                }
+                int* g = geo + 9 * lane;
+                g[0] = 0; g[1] = -2;
+                if (valid) {
+                    lsdn_geom(r, P.H, &G);
+                    g[1] = -1;               // no in-image row: a valid, empty scan (0, 0)
+                    if (G.yb >= G.ya) {
+                        g[0] = G.ya; g[1] = G.yb; g[2] = G.lefty; g[3] = G.righty; g[4] = (int)G.minx;
+                        g[5] = (int)G.fl; g[6] = (int)G.sl; g[7] = (int)G.fr; g[8] = (int)G.sr;
+                    }
                 }
             }
-            int nn = -1, kk = 0;
-            if (valid) {
-                lsdn_geom(rec, P.H, &G);
-                lsdn_count<1, PSL_NFA_GL>(ang, P.W, G, rec.theta, &rec.prec, lane, &nn, &kk);
+            __builtin_amdgcn_wave_barrier();
+            int nn[5], kk[5];
+            lsdn_count_trials<PSL_NFA_GL>(ang, P.W, (lds_cint*)geo, rec.theta, rec.prec, lane, nn, kk);
+            if (lane == 0) {
+#pragma unroll
+                for (int t = 0; t < 5; ++t) out[t] = geo[9 * t + 1] == -2 ? make_int2(-1, 0) : make_int2(nn[t], kk[t]);
             }
+            __builtin_amdgcn_wave_barrier();   // the group's geometries are rewritten by its next item
+        } else {                         // the first test: one scan
+            int nn = -1, kk = 0;
+            lsdn_geom(rec, P.H, &G);
+            lsdn_count<1, PSL_NFA_GL>(ang, P.W, G, rec.theta, &rec.prec, lane, &nn, &kk);
             if (lane == 0) out[j] = make_int2(nn, kk);
         }
     }

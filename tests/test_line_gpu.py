@@ -1,10 +1,11 @@
 """GPU parity of the line front-end vs the CPU oracle (oracle/line_oracle.cpp): every stage and the whole extractor are
 compared BIT FOR BIT (segments, keylines, LBD descriptors, line equations, fans), in both LSD refinement modes
 (LSD_REFINE_ADV = default, LSD_REFINE_STD).  The device calls no math library on this path: sinf / cosf / atanf / atan2f / tanf
-are glibc's float algorithms restated and pinned exhaustively against libm in the CPU suite; the double-precision functions
-whose glibc form cannot be reproduced offline (sin / cos of MergeTwoLines, log / exp / log10 of the NFA) are fdlibm's, within
-1-2 ulp of glibc (tests/test_f64math_cpu.py) - a difference that can reach an output only on an exact rounding tie; none
-occurs on any frame compared here.
+are glibc's float algorithms restated and pinned exhaustively against libm in the CPU suite, and so are the double sin / cos of
+MergeTwoLines and region2rect (glibc's table-driven algorithm restated, psl_sincos_glibc.h: 0 differences on 6e7 arguments);
+only the log / exp / log10 of the NFA, whose glibc form cannot be reproduced offline, are fdlibm's, within 1-2 ulp of glibc
+(tests/test_f64math_cpu.py) - a difference that can reach an output only on an exact tie of two NFA values; none occurs on any
+frame compared here, and the CPU suite counts decision flips over 240 frames (0).
 """
 import numpy as np
 import pytest
@@ -186,7 +187,7 @@ def _kl_equal(a, b, what, skip=()):
 @pytest.mark.parametrize("style,seed", [("struct", 3), ("desk", 4), ("struct", 8)])
 def test_merge_stage_on_oracle_segments(style, seed):
     """optimizeAndMergeLines_lsd on identical input segments (the STD segment list: more lines, more merges): every KeyLine field
-    bit-identical.  atanf / atan2f are glibc's algorithms restated; the double sin / cos of MergeTwoLines are fdlibm's (header)."""
+    bit-identical.  atanf / atan2f and the double sin / cos of MergeTwoLines are glibc's algorithms restated (header)."""
     import psl_slam_amd as P
     import oracle_lib
     img = _scene(style, seed)
