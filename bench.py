@@ -426,6 +426,10 @@ def main():
     scene = args.scene or ("sticks" if LINES else "desk")
     # ---- everything that forks worker processes happens BEFORE the GPU is touched: input frames and the CPU baseline
     gray256, depth8 = distinct_frames(W, H, scene, seed_for(rank), serial=profiled)
+    # continuity with rounds 1 - 2, whose headline ran on the 'struct' scene (29 keylines per frame): a few steps on it after the timed region
+    gray_prev = None
+    if LINES and scene == "sticks" and world == 1 and not args.host_io and not args.no_like_for_like and not profiled:
+        gray_prev, _ = distinct_frames(W, H, "struct", seed_for(rank))
     ND = len(gray256)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not profiled:
@@ -666,6 +670,19 @@ def main():
         lfl = {"frames_per_step_per_gpu": 6144, "steps": 5, "value": round(world * 6144 * 5 / d1, 1), "unit": "frames/s", "ms_per_step": round(d1 / 5 * 1e3, 3),
                "note": "same pipeline object, 6144 frames per launch (no gather in these steps)"}
         nB[0] = B
+    prev_scene = None
+    if gray_prev is not None and stream_l is None:
+        frames_d.copy_(torch.from_numpy(gray_prev).to(dev)[torch.from_numpy(idx).to(dev)])
+        step()
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        for _ in range(5):
+            step()
+        torch.cuda.synchronize(dev)
+        d1 = time.perf_counter() - t1
+        prev_scene = {"scene": "struct", "frames_per_step_per_gpu": B, "steps": 5, "value": round(B * 5 / d1, 1), "unit": "frames/s", "ms_per_step": round(d1 / 5 * 1e3, 3),
+                      "note": "the scene the headline of rounds 1 - 2 was measured on (overlapping polygons: ~29 keylines per frame), same pipeline object and "
+                              "batch; BENCH_r02: 52 495.5 frames/s"}
     segs = None
     if LINES and rank == 0:   # LSD segments in front of the merging, on 16 of the distinct frames (single-frame entry point)
         le1 = P.LINEextractor(1, 1.2, 200, 0.0, ctx=ctx)
@@ -725,6 +742,8 @@ def main():
         }
         if gather_info is not None:
             out["gather"] = gather_info
+        if prev_scene is not None:
+            out["previous_rounds_scene"] = prev_scene
         if lfl is not None:
             out["like_for_like"] = lfl
         if cpu is not None:
