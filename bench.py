@@ -684,7 +684,8 @@ def main():
                       "note": "the scene the headline of rounds 1 - 2 was measured on (overlapping polygons: ~29 keylines per frame), same pipeline object and "
                               "batch; BENCH_r02: 52 495.5 frames/s"}
     segs = None
-    if LINES and rank == 0:   # LSD segments in front of the merging, on 16 of the distinct frames (single-frame entry point)
+    if LINES and rank == 0 and not profiled:   # LSD segments in front of the merging, on 16 of the distinct frames (single-frame entry point; not under
+        # a profiler: its single-frame launches would dilute the per-kernel averages of the trace)
         le1 = P.LINEextractor(1, 1.2, 200, 0.0, ctx=ctx)
         segs = round(float(np.mean([len(le1.lsd_detect(gray256[i])) for i in range(0, ND, max(1, ND // 16))])), 1)
         le1.close()

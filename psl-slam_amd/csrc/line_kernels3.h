@@ -507,7 +507,13 @@ __global__ __launch_bounds__(256, 4) void k_lsd_nfa_count(LineParams P, const fl
 //                     (see the kernel).  -log10(sum) - logNT is left to k_lsd_nfa_select.
 // sstate[item] = (term, p_term), term == 0: no series (the value is in vals[item]; -inf for a trial the width guard excludes);
 // after the series: sstate[item].x = the binomial tail.
-struct LsdnSeries { double term, p_term; int n, i; unsigned slot, pad; };   // 32 B: one binomial tail to be summed
+// One binomial tail to be summed (40 B).  `stop`: rect_improve only ever asks of a trial's value v whether v > log_nfa, and log_nfa is
+// at least the value the rectangle carries into the phase; v = -log10(tail) - logNT can only fall while terms (all positive) are added,
+// so once the partial tail reaches `stop` = 10^(-log_nfa_in - logNT) (1 + 1e-6) the trial has lost whatever the remaining terms are,
+// and the series ends there (k_lsd_nfa_series stores +inf: -log10 gives -inf, never selected).  The margin 1e-6 (4e-7 in v) covers
+// the last-ulp non-monotonicity of the restated log10 (~2e-14) many times over; a trial that could still win is summed to the
+// reference's own truncation point, bit for bit.  The first test (its value BECOMES log_nfa) has stop = +inf.
+struct LsdnSeries { double term, p_term, stop; int n, i; unsigned slot, pad; };
 #define PSL_NFA_NCLS 12   // length classes of the series: class c holds predicted lengths in [2^c, 2^(c+1)) (c = 11: all longer ones)
 #define PSL_NFA_FG 16     // frames whose series of one class are summed by one workgroup
 
@@ -541,7 +547,7 @@ __global__ __launch_bounds__(256) void k_lsd_nfa_setup(LineParams P, LsdnTables 
     for (int item = tid; item < cnt * TR; item += 256) {
         const int idx = item / TR, j = item - idx * TR;
         const size_t o = (size_t)frame * P.maxseg + idx;
-        LsdnSeries e;
+        LsdnSeries e = {};
         e.pad = 0xffffffffu;   // no series
         if (PH == PSL_NFA_FIRST || keep[o] == 2) {
             const size_t slot = o * 5 + j;
@@ -568,6 +574,12 @@ __global__ __launch_bounds__(256) void k_lsd_nfa_setup(LineParams P, LsdnTables 
                         term = 0;
                     } else {   // (k + 1 <= n here: the series has at least one term)
                         e.term = term; e.p_term = p_term; e.n = n; e.i = k + 1; e.slot = (unsigned)(slot - (size_t)frame * lcap);
+                        e.stop = __builtin_inf();
+                        if (PH != PSL_NFA_FIRST) {
+                            const double lin = rects[o * PSL_LSD_RECT_F64 + 10];   // log_nfa the rectangle brings into this phase
+                            const double ex = (-lin - log_nt) * 2.30258509299404568402;
+                            if (ex < 0.0 && ex > -700.0) e.stop = psl_exp(ex) * (1.0 + 1e-6);   // tail <= 1: a threshold >= 1 never triggers
+                        }
                         e.pad = (unsigned)lsdn_series_class(n, k, p);
                         atomicAdd(&s_hist[e.pad], 1);
                     }
@@ -632,12 +644,12 @@ __global__ __launch_bounds__(256) void k_lsd_nfa_series(LineParams P, LsdnTables
     if (have_next) nxt = *locate(mine, &nxt_f);
     int n = 0, i = 0;
     double2* out = nullptr;
-    double term = 0, bin_tail = 0, p_term = 0;
+    double term = 0, bin_tail = 0, p_term = 0, stop_at = __builtin_inf();
     for (;;) {
         if (__popcll(__ballot(!running)) >= 8) {
             if (done) { out->x = bin_tail; done = false; }
             if (!running && have_next) {
-                n = nxt.n; i = nxt.i; term = nxt.term; bin_tail = nxt.term; p_term = nxt.p_term;
+                n = nxt.n; i = nxt.i; term = nxt.term; bin_tail = nxt.term; p_term = nxt.p_term; stop_at = nxt.stop;
                 out = sstate + (size_t)(f0 + nxt_f) * lcap + nxt.slot;
                 running = true;
                 mine += 256;
@@ -659,6 +671,7 @@ __global__ __launch_bounds__(256) void k_lsd_nfa_series(LineParams P, LsdnTables
             }
             i += 8;
             if (i > n) { running = false; done = true; }
+            if (bin_tail >= stop_at) { bin_tail = __builtin_inf(); running = false; done = true; }   // the trial has lost (LsdnSeries)
         } else if (running) {   // one term of the binomial tail
             const double bin_term = (double)(n - i + 1) / (double)i;
             const double mult_term = PSL_DMUL(bin_term, p_term);
@@ -677,6 +690,7 @@ __global__ __launch_bounds__(256) void k_lsd_nfa_series(LineParams P, LsdnTables
             }
             ++i;
             if (stop || i > n) { running = false; done = true; }
+            if (bin_tail >= stop_at) { bin_tail = __builtin_inf(); running = false; done = true; }
         }
     }
 }
@@ -700,6 +714,7 @@ __global__ __launch_bounds__(256) void k_lsd_nfa_select(LineParams P, double log
         // nfa() of trial t: the value k_lsd_nfa_setup left, or -log10(binomial tail) - logNT of its series
         auto value = [&](int t) {
             const double bt = sstate[o * 5 + t].x;
+            if (bt == __builtin_inf()) return -__builtin_inf();   // a series that ended at its `stop`: the trial cannot be selected
             return bt != 0 ? PSL_DSUB(-psl_log10(bt), log_nt) : vals[o * 5 + t];
         };
         if (PH == PSL_NFA_FIRST) logn = value(0);

@@ -199,6 +199,7 @@ struct GlueLds {
     uint32_t ring[34];
     int idx[PSL_GLUE_MAXPTS + 3];   // the RANSAC shuffle (`indexes`)
     int rank[PSL_GLUE_MAXPTS + 3];  // rank -> point of an inlier set
+    double term[3][24];             // psl_ordered_sum3: the terms of three ordered sums, one row each
 };
 
 __device__ __forceinline__ GlueP3 glue_pos(const GlueLds& S, int i) { return {S.pos[i][0], S.pos[i][1], S.pos[i][2]}; }
@@ -226,60 +227,104 @@ __device__ bool psl_verify_line(const GlueLds& S, unsigned long long mask, const
 }
 
 // Sum of `term` over lanes 0..m-1 in lane order (the reference's sequential accumulation), the same value in every lane.
-__device__ __forceinline__ double psl_ordered_sum(double term, int m) {
-    double s = 0;
-    for (int k = 0; k < m; ++k) {
-        const int lo = __builtin_amdgcn_readlane(__double2loint(term), k), hi = __builtin_amdgcn_readlane(__double2hiint(term), k);
-        s += __hiloint2double(hi, lo);
+// THREE sums over the first m lanes' terms, each added strictly in lane order starting from +0.0 (the reference's `s += x[k]` loops:
+// the rounding depends on the order), at the price of one: "terms in parallel, additions in series" - the terms are staged in three
+// LDS rows, lane r (r = 0, 1, 2) adds row r, so ONE chain of m dependent f64 adds serves the three sums (one readlane pair + add
+// per term and sum before: the n x 3 Jacobi SVD of isLineGood's refinement spent three quarters of its instructions there).  Rows
+// are padded with +0.0 to the batch of 8: x + (+0.0) == x for every value such a running sum can hold (it is never -0.0).
+__device__ __forceinline__ void psl_ordered_sum3(GlueLds& S, double t0, double t1, double t2, int m, double* s0, double* s1, double* s2) {
+    const int lane = threadIdx.x & 63;
+    if (lane < 24) {
+        const bool in = lane < m;
+        S.term[0][lane] = in ? t0 : 0.0; S.term[1][lane] = in ? t1 : 0.0; S.term[2][lane] = in ? t2 : 0.0;
     }
-    return s;
+    __builtin_amdgcn_wave_barrier();
+    const double* my = S.term[lane < 3 ? lane : 0];
+    double acc = 0;
+    for (int t = 0; t < m; t += 8) {   // m <= 21 (uniform)
+        double v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = my[t + k];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc += v[k];
+    }
+    __builtin_amdgcn_wave_barrier();   // the rows are rewritten by the next call
+    const int lo = __double2loint(acc), hi = __double2hiint(acc);
+    *s0 = __hiloint2double(__builtin_amdgcn_readlane(hi, 0), __builtin_amdgcn_readlane(lo, 0));
+    *s1 = __hiloint2double(__builtin_amdgcn_readlane(hi, 1), __builtin_amdgcn_readlane(lo, 1));
+    *s2 = __hiloint2double(__builtin_amdgcn_readlane(hi, 2), __builtin_amdgcn_readlane(lo, 2));
 }
 
-// psl_jacobi_rows with the matrix spread over the wave: lane k holds column k of the n (<= 3) rows, a[i] = At[i][k]
-// (0 in lanes >= m).  Products and rotations run in parallel over the columns; every sum is formed in column order, so
-// the result equals the sequential loop bit for bit.  W, Vt are uniform.
-__device__ void psl_jacobi_wave(double a[3], int m, int n, double W[3], double Vt[9]) {
+// OpenCV's JacobiSVDImpl_<double> on a matrix whose n <= 3 rows of length m <= 21 are spread over the lanes (lane k holds column k:
+// a[0..2]).  The reference's sweep order (0,1), (0,2), (1,2) and every sum's order are kept; a rotation's two new row norms and the
+// NEXT pair's scalar product - it is formed from the rows as the rotation leaves them, and nothing changes them before that pair is
+// looked at - share one psl_ordered_sum3.
+__device__ void psl_jacobi_wave(GlueLds& S, double a[3], int m, int n, double W[3], double Vt[9]) {
     const double eps = 2.220446049250313e-16 * 10;
     const int max_iter = m > 30 ? m : 30;
     double Wd[3] = {0, 0, 0};
+    auto get = [&](const double* v, int i) { return i == 0 ? v[0] : (i == 1 ? v[1] : v[2]); };
+    auto put = [&](double* v, int i, double x) { v[0] = i == 0 ? x : v[0]; v[1] = i == 1 ? x : v[1]; v[2] = i == 2 ? x : v[2]; };
+    {
+        double s0, s1, s2;   // rows i >= n hold zeros: their sums are the +0.0 Wd starts with
+        psl_ordered_sum3(S, a[0] * a[0], a[1] * a[1], a[2] * a[2], m, &s0, &s1, &s2);
+        Wd[0] = s0; Wd[1] = n > 1 ? s1 : 0.0; Wd[2] = n > 2 ? s2 : 0.0;
+    }
     for (int i = 0; i < n; ++i) {
-        Wd[i] = psl_ordered_sum(a[i] * a[i], m);
         for (int k = 0; k < n; ++k) Vt[i * 3 + k] = 0;
         Vt[i * 3 + i] = 1;
     }
+    const int npairs = n == 3 ? 3 : (n == 2 ? 1 : 0);
+    bool have_p = false;
+    double p_next = 0;
     for (int iter = 0; iter < max_iter; ++iter) {
         bool changed = false;
-        for (int i = 0; i < n - 1; ++i)
-            for (int j = i + 1; j < n; ++j) {
-                double aa = Wd[i], bb = Wd[j];
-                double p = psl_ordered_sum(a[i] * a[j], m);
-                if (fabs(p) <= eps * __dsqrt_rn(aa * bb)) continue;
-                p *= 2;
-                const double beta = aa - bb, gamma = __dsqrt_rn(p * p + beta * beta);
-                double c, sn;
-                if (beta < 0) {
-                    const double delta = (gamma - beta) * 0.5;
-                    sn = __dsqrt_rn(delta / gamma);
-                    c = p / (gamma * sn * 2);
-                } else {
-                    c = __dsqrt_rn((gamma + beta) / (gamma * 2));
-                    sn = p / (gamma * c * 2);
-                }
-                const double t0 = c * a[i] + sn * a[j];
-                const double t1 = -sn * a[i] + c * a[j];
-                a[i] = t0; a[j] = t1;
-                Wd[i] = psl_ordered_sum(t0 * t0, m);
-                Wd[j] = psl_ordered_sum(t1 * t1, m);
-                changed = true;
-                for (int k = 0; k < n; ++k) {
-                    const double v0 = c * Vt[i * 3 + k] + sn * Vt[j * 3 + k];
-                    const double v1 = -sn * Vt[i * 3 + k] + c * Vt[j * 3 + k];
-                    Vt[i * 3 + k] = v0; Vt[j * 3 + k] = v1;
-                }
+        for (int pr = 0; pr < npairs; ++pr) {
+            const int i = pr == 2 ? 1 : 0, j = pr == 0 ? 1 : 2;
+            const double ai = get(a, i), aj = get(a, j);
+            const double aa = get(Wd, i), bb = get(Wd, j);
+            double p;
+            if (have_p) p = p_next;
+            else { double d1, d2; psl_ordered_sum3(S, ai * aj, 0.0, 0.0, m, &p, &d1, &d2); }
+            have_p = false;
+            if (fabs(p) <= eps * __dsqrt_rn(aa * bb)) continue;
+            p *= 2;
+            const double beta = aa - bb, gamma = __dsqrt_rn(p * p + beta * beta);
+            double c, sn;
+            if (beta < 0) {
+                const double delta = (gamma - beta) * 0.5;
+                sn = __dsqrt_rn(delta / gamma);
+                c = p / (gamma * sn * 2);
+            } else {
+                c = __dsqrt_rn((gamma + beta) / (gamma * 2));
+                sn = p / (gamma * c * 2);
             }
+            const double t0 = c * ai + sn * aj;
+            const double t1 = -sn * ai + c * aj;
+            put(a, i, t0); put(a, j, t1);
+            // the pair the sweep looks at next (the first pair of the next sweep after the last one), on the rows as they are now
+            const int npr = pr + 1 < npairs ? pr + 1 : 0;
+            const int ni = npr == 2 ? 1 : 0, nj = npr == 0 ? 1 : 2;
+            double w0, w1;
+            psl_ordered_sum3(S, t0 * t0, t1 * t1, get(a, ni) * get(a, nj), m, &w0, &w1, &p_next);
+            put(Wd, i, w0); put(Wd, j, w1);
+            have_p = true;
+            changed = true;
+            for (int k = 0; k < n; ++k) {
+                const double v0 = c * Vt[i * 3 + k] + sn * Vt[j * 3 + k];
+                const double v1 = -sn * Vt[i * 3 + k] + c * Vt[j * 3 + k];
+                Vt[i * 3 + k] = v0; Vt[j * 3 + k] = v1;
+            }
+        }
         if (!changed) break;
     }
-    for (int i = 0; i < n; ++i) Wd[i] = __dsqrt_rn(psl_ordered_sum(a[i] * a[i], m));
+    {
+        double s0, s1, s2;
+        psl_ordered_sum3(S, a[0] * a[0], a[1] * a[1], a[2] * a[2], m, &s0, &s1, &s2);
+        Wd[0] = __dsqrt_rn(s0);
+        if (n > 1) Wd[1] = __dsqrt_rn(s1);
+        if (n > 2) Wd[2] = __dsqrt_rn(s2);
+    }
     for (int i = 0; i < n - 1; ++i) {
         int j = i;
         for (int k = i + 1; k < n; ++k)
@@ -301,15 +346,15 @@ __device__ void psl_jacobi_wave(double a[3], int m, int n, double W[3], double V
 __device__ void psl_line_svd(GlueLds& S, unsigned long long mask, const GlueP3& me, GlueP3* mean_out, GlueP3* drct_out) {
     const int lane = threadIdx.x & 63;
     const int n = __popcll(mask);
-    GlueP3 mean = {0, 0, 0};
-    for (unsigned long long mm = mask; mm; mm &= mm - 1) {  // mean = mean + pts[idx[i]].pos, in index order
-        const int L = (int)__ffsll((long long)mm) - 1;
-        mean = mean + glue_pos(S, L);
-    }
-    mean = mean * (1.0 / n);
     // rank r of an inlier = its column / row in the matrix
     if ((mask >> lane) & 1ull) S.rank[__popcll(mask & ((1ull << lane) - 1ull))] = lane;
     __builtin_amdgcn_wave_barrier();
+    GlueP3 mean = {0, 0, 0};
+    {   // mean = mean + pts[idx[i]].pos, in index order (= rank order): the three coordinate sums in one pass
+        const GlueP3 q = lane < n ? glue_pos(S, S.rank[lane]) : GlueP3{0, 0, 0};
+        psl_ordered_sum3(S, q.x, q.y, q.z, n, &mean.x, &mean.y, &mean.z);
+    }
+    mean = mean * (1.0 / n);
     double W[3], Vt[9], a[3] = {0, 0, 0};
     GlueP3 drct;
     if (n >= 3) {  // cv::SVD(P.t()), P.t() n x 3: A^T has 3 rows of length n, vt = V^T
@@ -317,7 +362,7 @@ __device__ void psl_line_svd(GlueLds& S, unsigned long long mask, const GlueP3& 
             const GlueP3 p = glue_pos(S, S.rank[lane]);
             a[0] = p.x - mean.x; a[1] = p.y - mean.y; a[2] = p.z - mean.z;
         }
-        psl_jacobi_wave(a, n, 3, W, Vt);
+        psl_jacobi_wave(S, a, n, 3, W, Vt);
         drct = {Vt[0], Vt[1], Vt[2]};
     } else {       // fewer rows than columns: the rows of P.t() themselves (n rows of length 3), vt = their normalised rotations
         if (lane < 3) {
@@ -326,7 +371,7 @@ __device__ void psl_line_svd(GlueLds& S, unsigned long long mask, const GlueP3& 
                 a[r] = lane == 0 ? p.x - mean.x : (lane == 1 ? p.y - mean.y : p.z - mean.z);
             }
         }
-        psl_jacobi_wave(a, 3, n, W, Vt);
+        psl_jacobi_wave(S, a, 3, n, W, Vt);
         const double r0 = a[0];
         drct.x = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(r0), 0), __builtin_amdgcn_readlane(__double2loint(r0), 0));
         drct.y = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(r0), 1), __builtin_amdgcn_readlane(__double2loint(r0), 1));

@@ -8,6 +8,12 @@ import pytest
 
 import synth_frames as sf
 
+try:   # PyTorch - and its copy of the HIP runtime - must be loaded BEFORE libpslfe in a process that uses both on the GPU (tests/conftest.py
+    import torch   # does this when the run is selected with -m gpu; at collection time it also holds for `pytest tests/test_gather_gpu.py`)
+    torch.cuda.is_available()
+except Exception:
+    pass
+
 pytestmark = pytest.mark.gpu
 
 
