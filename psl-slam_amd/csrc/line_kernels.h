@@ -247,7 +247,8 @@ __device__ __forceinline__ bool lsdg_aligned(double ad, double theta, double pre
 // pixels appended to an LDS list (any order: every output is a per-pixel store).  Phase B (thread = list entry): magnitude, angle,
 // records.  Phase C: the neighbour records of the pixels that have a defined pixel in their 3 x 3.
 __global__ __launch_bounds__(256) void k_lsd_grad(LineParams P, const double* __restrict__ scaled, float* __restrict__ angdeg,
-                                                   double* __restrict__ modgrad, float2* __restrict__ trig, float2* __restrict__ seedt, uint8_t* __restrict__ used, int nframes, int xcd) {
+                                                   double* __restrict__ modgrad, float2* __restrict__ trig, float2* __restrict__ seedt, uint8_t* __restrict__ used,
+                                                   int* __restrict__ weight, int nframes, int xcd) {
     __shared__ uint8_t s_def[PSL_GRAD_TH + 2][68];
     __shared__ float2 s_cs[PSL_GRAD_TH * 64];    // (cosf, sinf) of the tile's pixels, (0, 0) = undefined
     __shared__ float s_deg[PSL_GRAD_TH * 64];    // their angles: written to HBM as whole rows in phase C
@@ -317,6 +318,7 @@ __global__ __launch_bounds__(256) void k_lsd_grad(LineParams P, const double* __
     }
     __syncthreads();
     const int n = s_n;
+    if (weight && tid == 0 && n > 0) atomicAdd(weight + frame, n);   // the frame's defined pixels: what the region growing's work scales with (k_frame_order)
     for (int k = tid; k < n; k += 256) {
         const int px = s_px[k], r = px >> 6, c = px & 63;
         const size_t o = fo + (size_t)(y0 + r) * P.W + (x0 + c);
@@ -369,6 +371,45 @@ __global__ __launch_bounds__(256) void k_lsd_grad(LineParams P, const double* __
         angdeg[fo + (size_t)y * P.W + x] = s_deg[r * 64 + tx];
         if (any) trig[fo + (size_t)y * P.W + x] = s_cs[r * 64 + tx];
     }
+}
+
+// HEAVIEST FRAMES FIRST.  k_lsd_grow4 is one wave per frame and the hardware starts workgroups in index order as wave slots free up
+// - greedy list scheduling.  A launch of 12288 frames on 8192 slots (8 waves per SIMD) lasted 245 ms while its average wave lived
+// 127 ms (profiles/r03e: 22 % of the slot-time idle): the frames started last ran alone at the end.  Ordered by decreasing weight
+// (longest processing time first) the tail is made of the lightest frames.  weight = number of pixels with a defined gradient,
+// counted by k_lsd_grad (one atomic per tile); the order is a counting sort over 1024 weight classes by one workgroup (the order
+// inside a class is whatever the atomics give: it only affects the schedule, never a result).
+#ifndef PSL_FRAME_ORDER
+#define PSL_FRAME_ORDER 1   // 0: frames in index order (A/B, tools/ab_build.sh)
+#endif
+#define PSL_ORDER_CLASSES 1024
+__global__ __launch_bounds__(1024) void k_frame_order(const int* __restrict__ weight, int nframes, int wmax, int* __restrict__ order) {
+    __shared__ int s_cnt[PSL_ORDER_CLASSES];
+    __shared__ int s_w[17];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    s_cnt[tid] = 0;
+    __syncthreads();
+    const long long scale = wmax > 0 ? wmax : 1;
+    auto cls = [&](int w) {   // class 0 = heaviest
+        long long c = (long long)(w < 0 ? 0 : (w > wmax ? wmax : w)) * (PSL_ORDER_CLASSES - 1) / scale;
+        return PSL_ORDER_CLASSES - 1 - (int)c;
+    };
+    for (int f = tid; f < nframes; f += 1024) atomicAdd(&s_cnt[cls(weight[f])], 1);
+    __syncthreads();
+    const int mine = s_cnt[tid];
+    int inc = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(inc, o); if (lane >= o) inc += u; }
+    if (lane == 63) s_w[wave] = inc;
+    __syncthreads();
+    if (tid == 0) {
+        int acc = 0;
+        for (int k = 0; k < 16; ++k) { const int t = s_w[k]; s_w[k] = acc; acc += t; }
+    }
+    __syncthreads();
+    s_cnt[tid] = inc - mine + s_w[wave];   // exclusive start of the class
+    __syncthreads();
+    for (int f = tid; f < nframes; f += 1024) order[atomicAdd(&s_cnt[cls(weight[f])], 1)] = f;
 }
 
 struct LsdRect { double x1, y1, x2, y2, width, theta, dx, dy; };
@@ -886,11 +927,11 @@ __device__ __forceinline__ void psl_lsd_store_segment(const LineParams& P, doubl
 template <int HELPERS>
 __global__ __launch_bounds__(64 * (1 + HELPERS), HELPERS ? 1 : PSL_GROW_WAVES) void k_lsd_grow4(LineParams P, const float* __restrict__ angdeg, const double* __restrict__ modgrad,
                                                    const float2* __restrict__ trig, uint8_t* __restrict__ used, const float2* __restrict__ seedt, uint32_t* __restrict__ reg,
-                                                   float* __restrict__ seg, int* __restrict__ nseg, double* __restrict__ rects, int nframes) {
+                                                   float* __restrict__ seg, int* __restrict__ nseg, double* __restrict__ rects, int nframes, const int* __restrict__ order) {
     __shared__ uint32_t s_ring[PSL_LSD_RING];
     __shared__ double s_term[3 * 64];
     __shared__ uint32_t s_map[64];
-    const int frame = blockIdx.x, lane = threadIdx.x;
+    const int frame = order ? order[blockIdx.x] : (int)blockIdx.x, lane = threadIdx.x;   // many-frames launches: heaviest frames first (k_frame_order)
     const size_t npx = (size_t)P.W * P.H;
     const int words = (int)((npx + 31) >> 5);
     LsdW F;

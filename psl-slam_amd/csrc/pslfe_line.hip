@@ -41,6 +41,8 @@ struct pslfe_line {
     double* d_sctab = nullptr;    // psl_sincostab.inc
     double* d_rects = nullptr;    // LSD_REFINE_ADV: rectangles of k_lsd_grow4 for k_lsd_nfa
     int* d_nrect = nullptr;
+    int* d_weight = nullptr;   // [F] defined pixels per frame (k_lsd_grad) and [F] the frames by decreasing weight (k_frame_order)
+    int* d_order = nullptr;
     float* d_segtmp = nullptr;
     uint8_t* d_keep = nullptr;
     int2* d_counts = nullptr;     // (n, k) of the five trial rectangles of a rect_improve phase
@@ -76,12 +78,12 @@ struct pslfe_line {
         hipFree(d_seedt); d_seedt = nullptr;
         hipFree(d_used); d_used = nullptr;
         hipFree(d_in); hipFree(d_scaled); hipFree(d_angdeg); hipFree(d_modgrad); hipFree(d_reg);
-        hipFree(d_seg); hipFree(d_nseg); hipFree(d_rects); hipFree(d_nrect); hipFree(d_segtmp); hipFree(d_keep); hipFree(d_lgamma); hipFree(d_sctab);
+        hipFree(d_seg); hipFree(d_nseg); hipFree(d_rects); hipFree(d_nrect); hipFree(d_weight); hipFree(d_order); hipFree(d_segtmp); hipFree(d_keep); hipFree(d_lgamma); hipFree(d_sctab);
         d_sctab = nullptr; hipFree(d_counts); hipFree(d_vals); hipFree(d_sstate); hipFree(d_slist); hipFree(d_stmp); hipFree(d_lcount);
         d_counts = nullptr; d_vals = nullptr; d_sstate = nullptr; d_slist = nullptr; d_stmp = nullptr; d_lcount = nullptr;
         d_lgamma = nullptr;
         d_in = nullptr; d_scaled = nullptr; d_angdeg = nullptr; d_modgrad = nullptr; d_reg = nullptr;
-        d_seg = nullptr; d_nseg = nullptr; d_rects = nullptr; d_nrect = nullptr; d_segtmp = nullptr; d_keep = nullptr;
+        d_seg = nullptr; d_nseg = nullptr; d_rects = nullptr; d_nrect = nullptr; d_weight = nullptr; d_order = nullptr; d_segtmp = nullptr; d_keep = nullptr;
         gw = gh = 0;   // no geometry is prepared any more: the next call allocates again (or fails again) instead of
         last_nframes = 0;  // launching on freed memory
     }
@@ -167,6 +169,8 @@ struct pslfe_line {
         PSL_ALLOC(d_nseg, F * sizeof(int));
         PSL_ALLOC(d_rects, (size_t)Q.maxseg * PSL_LSD_RECT_F64 * sizeof(double) * F);
         PSL_ALLOC(d_nrect, F * sizeof(int));
+        PSL_ALLOC(d_weight, F * sizeof(int));
+        PSL_ALLOC(d_order, F * sizeof(int));
         PSL_ALLOC(d_segtmp, (size_t)Q.maxseg * 4 * sizeof(float) * F);
         PSL_ALLOC(d_keep, (size_t)Q.maxseg * F);
         PSL_ALLOC(d_counts, (size_t)Q.maxseg * 5 * sizeof(int2) * F);
@@ -255,7 +259,11 @@ struct pslfe_line {
             P.full_grad = nframes == 1;  // pslfe_line_debug_gradient reads the whole magnitude image of a single-frame call
             const unsigned gx = (P.W + 63) / 64, gy = (P.H + PSL_GRAD_TH - 1) / PSL_GRAD_TH;
             const int gxcd = F >= 8 ? 1 : 0;
-            k_lsd_grad<<<gxcd ? dim3(8, gx * gy, (F + 7) / 8) : dim3(gx, gy, F), 256, 0, st>>>(P, d_scaled, d_angdeg, d_modgrad, d_trig, d_seedt, d_used, (int)F, gxcd);
+            const bool ordered = PSL_FRAME_ORDER && F > PSL_GROW_HELPER_FRAMES;   // many-frames launches: k_lsd_grow4 takes the heaviest frames first
+            if (ordered) PSL_HIP(hipMemsetAsync(d_weight, 0, (size_t)F * sizeof(int), st));
+            k_lsd_grad<<<gxcd ? dim3(8, gx * gy, (F + 7) / 8) : dim3(gx, gy, F), 256, 0, st>>>(P, d_scaled, d_angdeg, d_modgrad, d_trig, d_seedt, d_used,
+                                                                                                 ordered ? d_weight : nullptr, (int)F, gxcd);
+            if (ordered) k_frame_order<<<1, 1024, 0, st>>>(d_weight, (int)F, P.W * P.H, d_order);
             PSL_STAGE_END(ctx, "line.lsd_grad");
         }
         P.refine = refine;
@@ -263,9 +271,10 @@ struct pslfe_line {
             PSL_STAGE_BEGIN(ctx, "line.lsd_grow");
             // LSD_REFINE_ADV: the kernel leaves rectangles (d_rects / d_nrect) for the NFA validation below
             if (F <= PSL_GROW_HELPER_FRAMES)  // few workgroups per XCD: three more waves each keep that XCD's L2 warm in front of the chain (line_kernels.h)
-                k_lsd_grow4<3><<<F, 256, 0, st>>>(P, d_angdeg, d_modgrad, d_trig, d_used, d_seedt, d_reg, d_seg, refine >= 2 ? d_nrect : d_nseg, d_rects, (int)F);
+                k_lsd_grow4<3><<<F, 256, 0, st>>>(P, d_angdeg, d_modgrad, d_trig, d_used, d_seedt, d_reg, d_seg, refine >= 2 ? d_nrect : d_nseg, d_rects, (int)F, nullptr);
             else
-                k_lsd_grow4<0><<<F, 64, 0, st>>>(P, d_angdeg, d_modgrad, d_trig, d_used, d_seedt, d_reg, d_seg, refine >= 2 ? d_nrect : d_nseg, d_rects, (int)F);
+                k_lsd_grow4<0><<<F, 64, 0, st>>>(P, d_angdeg, d_modgrad, d_trig, d_used, d_seedt, d_reg, d_seg, refine >= 2 ? d_nrect : d_nseg, d_rects, (int)F,
+                                                 PSL_FRAME_ORDER ? d_order : nullptr);
             PSL_STAGE_END(ctx, "line.lsd_grow");
         }
         if (refine >= 2) {

@@ -213,6 +213,103 @@ __global__ __launch_bounds__(256) void k_window_eval(MatchArgs A) {
     if (lane == 0) A.more[(size_t)pair * A.qstride + qi] = cnt > PSL_TOPK;
 }
 
+// Pass 1 for the many-frames launches, STAGED: one workgroup per frame copies what the window search reads of the frame - the CSR
+// grid, the keypoints' (x, y), octave and mvuRight, the descriptors: 72 KB for up to PSL_WS_CAP keypoints - into LDS once, coalesced,
+// and its 16 waves then work through the frame's queries (wave = query, as above) without touching HBM again except for the query
+// itself.  The wave-per-query kernel above issues three DEPENDENT global fetches per candidate (run bounds -> keypoint index ->
+// keypoint + descriptor) from 12 M independent waves per launch: 8.7 GB fetched for 0.9 GB of frames, two thirds of a wave's life
+// spent waiting (profiles/r03e_*).  Same arithmetic, same keys, same order.
+#define PSL_WS_CAP 1280
+__global__ __launch_bounds__(1024, 8) void k_window_eval_staged(MatchArgs A) {   // 64 VGPRs: two workgroups (72 KB of LDS each) per CU
+    __shared__ int s_gstart[PSL_GRID_CELLS + 1];
+    __shared__ uint16_t s_gidx[PSL_WS_CAP];
+    __shared__ float2 s_xy[PSL_WS_CAP];
+    __shared__ float s_ur[PSL_WS_CAP];
+    __shared__ uint8_t s_oct[PSL_WS_CAP];
+    __shared__ uint4 s_desc[PSL_WS_CAP * 2];
+    const int pair = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int nq = A.nq_arr ? A.nq_arr[pair] : A.nq_single;
+    nq = min(min(nq, A.qstride), PSL_QMAX);
+    const FrameView V = psl_frame_view(A.S, A.slot0 + pair);
+    const int n = min(V.n, PSL_WS_CAP);
+    for (int i = tid; i < n; i += 1024) {
+        s_xy[i] = *reinterpret_cast<const float2*>(&V.kps[i].x);
+        s_oct[i] = (uint8_t)V.kps[i].octave;
+        s_ur[i] = V.uright[i];
+        s_gidx[i] = (uint16_t)V.gidx[i];
+    }
+    for (int i = tid; i < 2 * n; i += 1024) s_desc[i] = reinterpret_cast<const uint4*>(V.desc)[i];
+    for (int c = tid; c <= PSL_GRID_CELLS; c += 1024) s_gstart[c] = V.gstart[c];
+    __syncthreads();
+    const FrameMeta& M = V.M;
+    const PslProjQuery* Q = A.q + (size_t)pair * A.qstride;
+    const uint4* QD = reinterpret_cast<const uint4*>(A.qdesc + (size_t)pair * A.qstride * 32);
+    const uint8_t* taken = A.taken ? A.taken + (size_t)pair * A.S.cap : nullptr;
+    // the next query is in flight while this one is evaluated
+    int qi = wave;
+    PslProjQuery qn = {};
+    uint4 qa = {}, qb = {};
+    if (qi < nq) { qn = Q[qi]; qa = QD[2 * (size_t)qi]; qb = QD[2 * (size_t)qi + 1]; }
+    for (; qi < nq; qi += 16) {
+        const PslProjQuery q = qn;
+        const uint32_t qd[8] = {qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w};
+        if (qi + 16 < nq) { qn = Q[qi + 16]; qa = QD[2 * (size_t)(qi + 16)]; qb = QD[2 * (size_t)(qi + 16) + 1]; }
+        // psl_window_cols on the staged grid
+        const float r = q.radius;
+        const int minCX = max(0, (int)__builtin_floorf(PSL_FMUL(PSL_FSUB(PSL_FSUB(q.u, M.minX), r), M.invW)));
+        const int maxCX = min(PSL_GRID_COLS - 1, (int)__builtin_ceilf(PSL_FMUL(PSL_FADD(PSL_FSUB(q.u, M.minX), r), M.invW)));
+        const int minCY = max(0, (int)__builtin_floorf(PSL_FMUL(PSL_FSUB(PSL_FSUB(q.v, M.minY), r), M.invH)));
+        const int maxCY = min(PSL_GRID_ROWS - 1, (int)__builtin_ceilf(PSL_FMUL(PSL_FADD(PSL_FSUB(q.v, M.minY), r), M.invH)));
+        const bool window = minCX < PSL_GRID_COLS && maxCX >= 0 && minCY < PSL_GRID_ROWS && maxCY >= 0;
+        WindowCols W;
+        W.start = 0;
+        int len = 0;
+        if (window && minCX + lane <= maxCX) {
+            const int ix = minCX + lane;
+            W.start = s_gstart[ix * PSL_GRID_ROWS + minCY];
+            len = s_gstart[ix * PSL_GRID_ROWS + maxCY + 1] - W.start;
+        }
+        int incl = len;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(incl, o); if (lane >= o) incl += u; }
+        W.incl = incl;
+        W.excl = incl - len;
+        W.T = __shfl(incl, 63);
+        W.checkLevels = (q.min_level > 0) || (q.max_level >= 0);
+        uint32_t best = PSL_KEY_INF;  // lanes 0..PSL_TOPK-1: running smallest keys, ascending
+        int cnt = 0;
+        for (int base = 0; base < W.T; base += 64) {
+            // psl_window_key on the staged frame
+            const int p = psl_window_pos(W, base + lane);
+            uint32_t key = PSL_KEY_INF;
+            if (p >= 0) {
+                const int i2 = s_gidx[p];
+                const float2 xy = s_xy[i2];
+                const int octave = s_oct[i2];
+                const float ur = s_ur[i2];
+                const uint4 d0 = s_desc[2 * i2], d1 = s_desc[2 * i2 + 1];
+                bool ok = i2 < n;
+                if (W.checkLevels) ok = ok && !(octave < q.min_level) && !(q.max_level >= 0 && octave > q.max_level);
+                ok = ok && (__builtin_fabsf(PSL_FSUB(xy.x, q.u)) < r && __builtin_fabsf(PSL_FSUB(xy.y, q.v)) < r);
+                if (taken) ok = ok && !taken[i2];
+                if (!A.no_stereo) ok = ok && !(ur > 0 && __builtin_fabsf(PSL_FSUB(q.ur, ur)) > r);
+                const int dist = __popc(qd[0] ^ d0.x) + __popc(qd[1] ^ d0.y) + __popc(qd[2] ^ d0.z) + __popc(qd[3] ^ d0.w) +
+                                 __popc(qd[4] ^ d1.x) + __popc(qd[5] ^ d1.y) + __popc(qd[6] ^ d1.z) + __popc(qd[7] ^ d1.w);
+                if (ok) key = ((uint32_t)dist << 16) | (uint32_t)p;
+            }
+            cnt += __popcll(__ballot(key != PSL_KEY_INF));
+            key = psl_wave_sort(key);
+            if (base > 0) {  // merge this round's smallest with the running ones
+                const uint32_t o = __shfl(key, (lane - PSL_TOPK) & 63);
+                key = psl_wave_sort(lane < PSL_TOPK ? best : (lane < 2 * PSL_TOPK ? o : PSL_KEY_INF));
+            }
+            best = key;
+        }
+        if (lane < PSL_TOPK) A.topk[((size_t)pair * A.qstride + qi) * PSL_TOPK + lane] = best;
+        if (lane == 0) A.more[(size_t)pair * A.qstride + qi] = cnt > PSL_TOPK;
+    }
+}
+
 // Pass 2: one workgroup per frame resolves the sequential semantics by a fixpoint on "taken by an earlier
 // query".  A thread owns QM/BS queries and keeps their cached candidate lists (key, keypoint, octave) in
 // registers, so an iteration touches only LDS: phase A picks every query's best candidate not taken by an
@@ -788,7 +885,10 @@ int pslfe_orb_search_by_projection_last_device(pslfe_frame* cur, int slot0, int 
     A.topk = cur->d_topk; A.more = cur->d_more;
     {
         PSL_STAGE_BEGIN(cur->ctx, "match.window");
-        k_window_eval<<<dim3((std::min(qstride, PSL_QMAX) + 3) / 4, npairs), 256, 0, cur->ctx->stream>>>(A);
+        if (cur->cap <= PSL_WS_CAP && npairs >= 64)   // many frames of at most 1280 keypoints: the frame staged in LDS, one workgroup per frame
+            k_window_eval_staged<<<npairs, 1024, 0, cur->ctx->stream>>>(A);
+        else
+            k_window_eval<<<dim3((std::min(qstride, PSL_QMAX) + 3) / 4, npairs), 256, 0, cur->ctx->stream>>>(A);
         // one 1024-thread workgroup per frame: measured faster than 512-thread workgroups at 256 and at 4096 frames
         k_window_resolve<0, PSL_QMAX, 1024><<<npairs, 1024, 0, cur->ctx->stream>>>(A);
         PSL_STAGE_END(cur->ctx, "match.window");

@@ -17,7 +17,7 @@ def pytest_sessionstart(session):
     """A process that uses both PyTorch and libpslfe on the GPU (tests/test_gather_gpu.py, as bench.py) must load PyTorch - and
     with it PyTorch's copy of the HIP runtime - FIRST: loaded after libpslfe it finds no device."""
     m = session.config.getoption("-m") or ""
-    if "gpu" in m and "not gpu" not in m:
+    if ("gpu" in m and "not gpu" not in m) or (os.path.exists("/dev/kfd") and "not gpu" not in m):   # a GPU box, however the tests were selected
         try:
             import torch
             torch.cuda.is_available()

@@ -267,3 +267,40 @@ def test_search_by_bow_empty_and_bad_input():
     assert nm == 0 and len(match) == 0
     with pytest.raises(P.PslfeError):  # a run that leaves the feature vector
         P.ORBmatcher(0.7, True).SearchByBoW(g, 0, np.arange(10, dtype=np.int32), [(5, 10)], [0.0], d0[:1])
+
+
+def test_many_frames_search_by_projection_staged_window_equals_oracle():
+    """The many-frames launch of SearchByProjection(cur,last) (>= 64 frames of <= 1280 keypoints: k_window_eval_staged, the frame's
+    grid / keypoints / descriptors in LDS, one workgroup per frame) through the batched pipeline: ORB extraction of 96 frames,
+    frame f matched against frame f - 1; sampled frames equal the oracle (keypoints, descriptors, matches), and the whole match
+    table equals the one the wave-per-query kernel gives for the same frames in launches of 48 (< 64: not staged)."""
+    import torch
+    import psl_slam_amd as P
+    import batch_pipeline as BP
+    B, w, h = 96, 640, 480
+    frames = []
+    for style, seed in (("desk", 31), ("struct", 32), ("sticks", 33)):
+        sc = sf.Scene(w, h, style, seed)
+        frames += [sc.gray(t) for t in range(8)]
+    gray = np.ascontiguousarray(np.stack(frames * (B // len(frames)), 0))
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.Stream(dev)
+    torch.cuda.set_stream(stream)
+    pipe = BP.BatchPipeline(P, torch, dev, stream, 0, B, w, h, lines=False)
+    assert pipe.cap <= 1280
+    d_gray = torch.from_numpy(gray).to(dev)
+    pipe.step(d_gray.data_ptr())
+    torch.cuda.synchronize(dev)
+    match_staged, nm_staged = pipe.match.cpu().numpy().copy(), pipe.nmatches.cpu().numpy().copy()
+    cache = {}
+    for f in (0, 1, 7, 8, 16, 23, 24, 95):   # incl. the cuts between scenes (frame 8: struct after desk) and the cyclic predecessor of frame 0
+        pf = (f - 1) % B
+        ref = BP.oracle_frame((pf % 24, gray[pf]), (f % 24, gray[f]), None, f, w, h, False, pipe.cam, cache=cache)
+        BP.compare_frame(pipe.fetch_frame(f), ref, f"frame {f}: ")
+    assert int(nm_staged.sum()) > 100 * B // 4
+    # the same frames in two launches of 48: the wave-per-query kernel; frame 0 / 48 see another predecessor there, every other row is equal
+    for half in (0, 1):
+        pipe.step(d_gray[48 * half:].data_ptr(), None, 48)
+        torch.cuda.synchronize(dev)
+        m = pipe.match.cpu().numpy()[:48]
+        assert np.array_equal(m[1:], match_staged[48 * half + 1:48 * half + 48]), f"half {half}: staged and wave-per-query match tables differ"
