@@ -672,7 +672,12 @@ def main():
         nB[0] = B
     prev_scene = None
     if gray_prev is not None and stream_l is None:
-        frames_d.copy_(torch.from_numpy(gray_prev).to(dev)[torch.from_numpy(idx).to(dev)])
+        tmp = torch.from_numpy(gray_prev).to(dev)
+        for lo in range(0, B, ND):   # the 256 distinct frames repeated, without a second batch-sized temporary
+            n_ = min(ND, B - lo)
+            frames_d[lo:lo + n_].copy_(tmp[:n_])
+        del tmp
+        torch.cuda.empty_cache()
         step()
         torch.cuda.synchronize(dev)
         t1 = time.perf_counter()

@@ -507,13 +507,15 @@ __global__ __launch_bounds__(256, 4) void k_lsd_nfa_count(LineParams P, const fl
 //                     (see the kernel).  -log10(sum) - logNT is left to k_lsd_nfa_select.
 // sstate[item] = (term, p_term), term == 0: no series (the value is in vals[item]; -inf for a trial the width guard excludes);
 // after the series: sstate[item].x = the binomial tail.
-// One binomial tail to be summed (40 B).  `stop`: rect_improve only ever asks of a trial's value v whether v > log_nfa, and log_nfa is
+// One binomial tail to be summed (32 B).  `stop`: rect_improve only ever asks of a trial's value v whether v > log_nfa, and log_nfa is
 // at least the value the rectangle carries into the phase; v = -log10(tail) - logNT can only fall while terms (all positive) are added,
 // so once the partial tail reaches `stop` = 10^(-log_nfa_in - logNT) (1 + 1e-6) the trial has lost whatever the remaining terms are,
 // and the series ends there (k_lsd_nfa_series stores +inf: -log10 gives -inf, never selected).  The margin 1e-6 (4e-7 in v) covers
 // the last-ulp non-monotonicity of the restated log10 (~2e-14) many times over; a trial that could still win is summed to the
-// reference's own truncation point, bit for bit.  The first test (its value BECOMES log_nfa) has stop = +inf.
-struct LsdnSeries { double term, p_term, stop; int n, i; unsigned slot, pad; };
+// reference's own truncation point, bit for bit.  The first test (its value BECOMES log_nfa) has stop = +inf.  `stop` is kept as the next
+// float ABOVE the threshold (never below FLT_MIN): a larger threshold only stops later.  `pad`: the length class, 0xffff = no series.
+struct LsdnSeries { double term, p_term; int n, i; float stop; uint16_t slot, pad; };
+static_assert(sizeof(LsdnSeries) == 32, "LsdnSeries is 32 bytes");
 #define PSL_NFA_NCLS 12   // length classes of the series: class c holds predicted lengths in [2^c, 2^(c+1)) (c = 11: all longer ones)
 #define PSL_NFA_FG 16     // frames whose series of one class are summed by one workgroup
 
@@ -548,7 +550,7 @@ __global__ __launch_bounds__(256) void k_lsd_nfa_setup(LineParams P, LsdnTables 
         const int idx = item / TR, j = item - idx * TR;
         const size_t o = (size_t)frame * P.maxseg + idx;
         LsdnSeries e = {};
-        e.pad = 0xffffffffu;   // no series
+        e.pad = 0xffffu;   // no series
         if (PH == PSL_NFA_FIRST || keep[o] == 2) {
             const size_t slot = o * 5 + j;
             double v = 0, term = 0, p_term = 0;
@@ -573,14 +575,19 @@ __global__ __launch_bounds__(256) void k_lsd_nfa_setup(LineParams P, LsdnTables 
                         v = (double)k > PSL_DMUL((double)n, p) ? PSL_DSUB(-log1term / 2.30258509299404568402, log_nt) : -log_nt;
                         term = 0;
                     } else {   // (k + 1 <= n here: the series has at least one term)
-                        e.term = term; e.p_term = p_term; e.n = n; e.i = k + 1; e.slot = (unsigned)(slot - (size_t)frame * lcap);
+                        e.term = term; e.p_term = p_term; e.n = n; e.i = k + 1; e.slot = (uint16_t)(slot - (size_t)frame * lcap);   // < maxseg * 5 <= 65535
                         e.stop = __builtin_inf();
                         if (PH != PSL_NFA_FIRST) {
                             const double lin = rects[o * PSL_LSD_RECT_F64 + 10];   // log_nfa the rectangle brings into this phase
                             const double ex = (-lin - log_nt) * 2.30258509299404568402;
-                            if (ex < 0.0 && ex > -700.0) e.stop = psl_exp(ex) * (1.0 + 1e-6);   // tail <= 1: a threshold >= 1 never triggers
+                            if (ex < 0.0 && ex > -700.0) {   // tail <= 1: a threshold >= 1 never triggers
+                                const double th = psl_exp(ex) * (1.0 + 1e-6);
+                                float tf = (float)th;
+                                if ((double)tf < th) tf = __uint_as_float(__float_as_uint(tf) + 1u);   // round up (th > 0)
+                                e.stop = tf < 1.17549435e-38f ? 1.17549435e-38f : tf;
+                            }
                         }
-                        e.pad = (unsigned)lsdn_series_class(n, k, p);
+                        e.pad = (uint16_t)lsdn_series_class(n, k, p);
                         atomicAdd(&s_hist[e.pad], 1);
                     }
                 }
@@ -599,7 +606,7 @@ __global__ __launch_bounds__(256) void k_lsd_nfa_setup(LineParams P, LsdnTables 
     __syncthreads();
     for (int item = tid; item < cnt * TR; item += 256) {
         const LsdnSeries e = TMP[item];
-        if (e.pad != 0xffffffffu) L[atomicAdd(&s_cur[e.pad], 1)] = e;
+        if (e.pad != 0xffffu) L[atomicAdd(&s_cur[e.pad], 1)] = e;
     }
 }
 
@@ -649,7 +656,7 @@ __global__ __launch_bounds__(256) void k_lsd_nfa_series(LineParams P, LsdnTables
         if (__popcll(__ballot(!running)) >= 8) {
             if (done) { out->x = bin_tail; done = false; }
             if (!running && have_next) {
-                n = nxt.n; i = nxt.i; term = nxt.term; bin_tail = nxt.term; p_term = nxt.p_term; stop_at = nxt.stop;
+                n = nxt.n; i = nxt.i; term = nxt.term; bin_tail = nxt.term; p_term = nxt.p_term; stop_at = (double)nxt.stop;
                 out = sstate + (size_t)(f0 + nxt_f) * lcap + nxt.slot;
                 running = true;
                 mine += 256;

@@ -3,15 +3,18 @@
 set -e
 t=$1
 cd $GRAFT_REPO_ROOT
-python bench.py > gpurun_out/${t}_bench_lines.json 2> gpurun_out/${t}_bench_lines.err
-python bench.py --workload orb > gpurun_out/${t}_bench_orb.json 2> gpurun_out/${t}_bench_orb.err
-python bench.py --workload dropin > gpurun_out/${t}_bench_dropin.json 2> gpurun_out/${t}_bench_dropin.err
-python bench.py --workload tracking > gpurun_out/${t}_bench_tracking.json 2> gpurun_out/${t}_bench_tracking.err
-python bench.py --host-io --batch 12288 --no-cpu-baseline > gpurun_out/${t}_bench_b12288io.json 2> gpurun_out/${t}_bench_b12288io.err
-python bench.py --host-io --no-cpu-baseline > gpurun_out/${t}_bench_b6144io.json 2> gpurun_out/${t}_bench_b6144io.err
-python bench.py --batch 6144 --no-cpu-baseline > gpurun_out/${t}_bench_lines_b6144.json 2> gpurun_out/${t}_bench_lines_b6144.err
-python bench.py --batch 32 --host-io --no-cpu-baseline > gpurun_out/${t}_bench_b32io.json 2> gpurun_out/${t}_bench_b32io.err
-for f in lines lines_b6144 orb dropin tracking b12288io b6144io b32io; do python - gpurun_out/${t}_bench_$f.json <<'P'
+run() { name=$1; shift; python bench.py "$@" > gpurun_out/${t}_bench_$name.json 2> gpurun_out/${t}_bench_$name.err || { tail -5 gpurun_out/${t}_bench_$name.err; exit 1; }; }
+run lines
+run orb --workload orb
+run struct --scene struct --no-cpu-baseline --no-like-for-like
+run dropin --workload dropin
+run dropin_K32 --workload dropin --lookahead 32 --no-cpu-baseline --steps 128
+run tracking --workload tracking
+run tracking_K32 --workload tracking --lookahead 32 --no-cpu-baseline --steps 128
+run b12288io --host-io --batch 12288 --no-cpu-baseline --no-like-for-like
+run b6144io --host-io --batch 6144 --no-cpu-baseline --no-like-for-like
+run b32io --batch 32 --host-io --no-cpu-baseline --no-like-for-like
+for f in lines orb struct dropin dropin_K32 tracking tracking_K32 b12288io b6144io b32io; do python - gpurun_out/${t}_bench_$f.json <<'P'
 import json, sys
 d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
 print(sys.argv[1].split('_bench_')[1], d['value'], d['unit'], d['ms_per_step'], d.get('parity_checked_frames'), d.get('roofline', {}).get('frac'))

@@ -73,7 +73,9 @@ def run(gray, depth, nfeatures, nlines, lines, budget_s=20.0, min_frames=200, wa
            "ms_per_frame": {"median": round(float(np.median(timed)), 3), "mean": round(float(timed.mean()), 3)},
            "calls_ms_mean": {k: round(v / stage_n, 3) for k, v in stage.items()},
            "sample": f"{ntimed} frames {gray.shape[2]}x{gray.shape[1]} after {warm} warm-up frames, synthetic stream, the Frame::Frame + TrackWithMotionModel "
-                     f"call sequence of tools/dropin_harness.py:oracle_sequence ({'ORB + lines' if lines else 'ORB only'}), oracle/ built {build}, 1 thread",
+                     f"call sequence of tools/dropin_harness.py:oracle_sequence ({'ORB + lines' if lines else 'ORB only'}; a SUPERSET of the batched GPU step's call list: "
+                     f"it adds UndistortKeyPoints / ComputeStereoFromRGBD / grid, SearchByGeomNApearance and AssociatePlanesByBoundary, about 0.3 ms per frame), "
+                     f"oracle/ built {build}, 1 thread",
            "cpu_model": cpu_model()}
     # (b) one stream per core
     try:
