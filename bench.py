@@ -454,7 +454,7 @@ def main():
     # as its longest frames) when the device's FREE memory holds it: 22.9 MB per frame (pipeline buffers 19.5 + 4.4, gray, depth f32) +
     # the gather's buffers (N > 1: two send buffers per rank, ONE receive buffer of world x batch records on rank 0; --host-io: pinned
     # staging is host memory, the u16 depth copy 0.6 MB per frame) + 6 GB of slack.  Every rank takes the same decision (MIN over ranks).
-    REC_BYTES = 85248
+    REC_BYTES = 104 * 1024   # upper estimate of one result record (101 120 B at 1100 keypoint rows / 200 lines / 512 fans / 64 planes)
     def need_bytes(b):
         n = b * 22.9e6 + 6e9
         if world > 1 or args.host_io:
@@ -527,7 +527,7 @@ def main():
     torch.cuda.synchronize(dev)
     if world > 1 or args.host_io:
         layout = pipe.record_layout(mg)
-        assert layout.bytes == REC_BYTES or not LINES, layout.bytes
+        assert layout.bytes <= REC_BYTES, layout.bytes
         root = None if args.gather == "all" else 0
 
         def bcast(uid, ok):   # rank 0's 128-byte ncclUniqueId and whether it got one, to every rank (always the SAME collective on all ranks)

@@ -379,6 +379,7 @@ __global__ __launch_bounds__(256) void k_lsd_grad(LineParams P, const double* __
 // (longest processing time first) the tail is made of the lightest frames.  weight = number of pixels with a defined gradient,
 // counted by k_lsd_grad (one atomic per tile); the order is a counting sort over 1024 weight classes by one workgroup (the order
 // inside a class is whatever the atomics give: it only affects the schedule, never a result).
+#define PSL_LSD_SUBBATCH 2048   // frames whose f64 working image is resident between k_lsd_scale_tiled and k_lsd_grad (pslfe_line.hip: run_lsd)
 #ifndef PSL_FRAME_ORDER
 #define PSL_FRAME_ORDER 1   // 0: frames in index order (A/B, tools/ab_build.sh)
 #endif
@@ -598,6 +599,84 @@ __device__ __forceinline__ int lsdg_decide(unsigned long long& cand, unsigned lo
     return cx;
 }
 
+#ifndef PSL_GROW_ASM_POPS
+#define PSL_GROW_ASM_POPS 1   // 0: the pop loop as compiled C++ around lsdg_decide (A/B, tools/ab_build.sh)
+#endif
+// lsdg_decide with the loop over the popped entries around it (round 3): per popped entry the compiler spent ~23 scalar instructions on
+// "which lane holds entry i, is it in the window's interior, which of its neighbours are live" (every uniform bool a 64-bit mask, a
+// compare, a select and a branch); written out it is 9.  Runs pops and decisions until no lane of the window's interior holds entry i
+// (returns -1: the round is over) or a candidate c falls inside the decision margin (returns c with the popped entry's remaining
+// candidates in `cand`: the caller runs the reference's arithmetic for c and calls again, which resumes with `cand`).
+__device__ __forceinline__ int lsdg_pops(unsigned long long& cand, unsigned long long& live, unsigned long long& RA, unsigned long long& RN, int& fresh,
+                                         int& reg_size, int& i, float& sumdx, float& sumdy, int& seq, float cs, float sn, float t_hi, float t_lo,
+                                         unsigned long long interior) {
+    int cx, c, sa, sb;
+    float t0, t1, t2;
+    unsigned long long tm;
+    const unsigned long long k3x3 = 0x070707ull;
+    asm volatile(
+        "s_mov_b32 %[cx], -1\n\t"
+        "s_cmp_lg_u64 %[cand], 0\n\t"
+        "s_cbranch_scc1 .Ltop%=\n\t"
+        ".Lpop%=:\n\t"
+        "v_cmp_eq_u32 vcc, %[i], %[seq]\n\t"
+        "s_and_b64 %[tm], vcc, %[inter]\n\t"
+        "s_cbranch_scc0 .Ldone%=\n\t"
+        "s_ff1_i32_b64 %[c], %[tm]\n\t"
+        "s_add_i32 %[c], %[c], -9\n\t"
+        "s_lshl_b64 %[tm], %[k3], %[c]\n\t"
+        "s_add_i32 %[i], %[i], 1\n\t"
+        "s_and_b64 %[cand], %[tm], %[live]\n\t"
+        "s_cbranch_scc0 .Lpop%=\n\t"
+        ".Ltop%=:\n\t"
+        "s_cmp_lg_u32 %[fresh], 0\n\t"
+        "s_cbranch_scc1 .Lhave%=\n\t"
+        "v_mul_f32 %[t0], %[sy], %[sn]\n\t"
+        "v_mul_f32 %[t1], %[sy], %[cs]\n\t"
+        "v_fmac_f32 %[t0], %[sx], %[cs]\n\t"
+        "v_fma_f32 %[t1], %[sx], %[sn], -%[t1]\n\t"
+        "v_max_f32 %[t0], 0, %[t0]\n\t"
+        "v_mul_f32 %[t2], %[thi], %[t0]\n\t"
+        "v_mul_f32 %[t0], %[tlo], %[t0]\n\t"
+        "v_cmp_lt_f32 %[RA], |%[t1]|, %[t2]\n\t"
+        "v_cmp_ge_f32 %[RN], |%[t1]|, %[t0]\n\t"
+        "s_mov_b32 %[fresh], 1\n\t"
+        ".Lhave%=:\n\t"
+        "s_andn2_b64 %[tm], %[cand], %[RN]\n\t"
+        "s_cbranch_scc0 .Lnone%=\n\t"
+        "s_ff1_i32_b64 %[c], %[tm]\n\t"
+        "s_lshl_b64 %[tm], -2, %[c]\n\t"
+        "s_and_b64 %[cand], %[cand], %[tm]\n\t"
+        "s_bitcmp1_b64 %[RA], %[c]\n\t"
+        "s_cbranch_scc0 .Lamb%=\n\t"
+        "s_mov_b32 m0, %[c]\n\t"
+        "v_readlane_b32 %[sa], %[cs], %[c]\n\t"
+        "v_readlane_b32 %[sb], %[sn], %[c]\n\t"
+        "v_writelane_b32 %[seq], %[rs], m0\n\t"
+        "s_nop 0\n\t"
+        "v_add_f32 %[sx], %[sa], %[sx]\n\t"
+        "v_add_f32 %[sy], %[sb], %[sy]\n\t"
+        "s_bitset0_b64 %[live], %[c]\n\t"
+        "s_add_i32 %[rs], %[rs], 1\n\t"
+        "s_mov_b32 %[fresh], 0\n\t"
+        "s_cmp_lg_u64 %[cand], 0\n\t"
+        "s_cbranch_scc1 .Ltop%=\n\t"
+        "s_branch .Lpop%=\n\t"
+        ".Lamb%=:\n\t"
+        "s_mov_b32 %[cx], %[c]\n\t"
+        "s_branch .Ldone%=\n\t"
+        ".Lnone%=:\n\t"
+        "s_mov_b64 %[cand], 0\n\t"
+        "s_branch .Lpop%=\n\t"
+        ".Ldone%=:\n\t"
+        : [cand] "+s"(cand), [live] "+s"(live), [RA] "+s"(RA), [RN] "+s"(RN), [fresh] "+s"(fresh), [rs] "+s"(reg_size), [i] "+s"(i), [sx] "+v"(sumdx),
+          [sy] "+v"(sumdy), [seq] "+v"(seq), [cx] "=&s"(cx), [c] "=&s"(c), [sa] "=&s"(sa), [sb] "=&s"(sb), [tm] "=&s"(tm), [t0] "=&v"(t0), [t1] "=&v"(t1),
+          [t2] "=&v"(t2)
+        : [cs] "v"(cs), [sn] "v"(sn), [thi] "v"(t_hi), [tlo] "v"(t_lo), [inter] "s"(interior), [k3] "s"(k3x3)
+        : "scc", "m0", "vcc");
+    return cx;
+}
+
 // `regrow`: the refinement's second growth - its releases of the region's pixels must have completed, nothing is pending.
 // `touched`: set when the region took a pixel whose raster index lies in (seed, trip_end): only then has the seed scan to look
 // at the `used` words of its current 256-pixel trip again.
@@ -665,6 +744,7 @@ __device__ int lsdg_region_grow4(const LsdW& F, int sx, int sy, double* reg_angl
         unsigned long long live = __ballot(inside && (cs != 0.f || sn != 0.f) && !ub && !pa && seq < 0);
         unsigned long long RA = 0ull, RN = 0ull;  // valid while the sums are the ones they were computed from (`fresh`)
         int fresh = 0;
+#if defined(PSL_GROW_STATS) || !PSL_GROW_ASM_POPS   // the same loop as the compiler writes it (diagnostic counters; A/B)
         for (;;) {
             const unsigned long long m = __ballot(seq == i) & F.interior;  // in the window, and in its 6 x 6 interior
             if (!m) break;  // (also when i == reg_size: no lane holds an index that does not exist yet)
@@ -690,6 +770,23 @@ __device__ int lsdg_region_grow4(const LsdW& F, int sx, int sy, double* reg_angl
                 fresh = 0;
             }
         }
+#else
+        unsigned long long cand = 0ull;
+        for (;;) {
+            const int c = lsdg_pops(cand, live, RA, RN, fresh, reg_size, i, sumdx, sumdy, seq, cs, sn, fc.t_hi, fc.t_lo, F.interior);
+            if (c < 0) break;   // no lane of the window's interior holds entry i: the round is over
+            // lane c is within the margin of the threshold: the reference's arithmetic
+            if (rs_angle != reg_size) { reg_deg = psl_fast_atan2(sumdy, sumdx); rs_angle = reg_size; }
+            const double ad = PSL_DMUL((double)F.ang[cidx], PSL_DEG2RAD), th = PSL_DMUL((double)reg_deg, PSL_DEG2RAD);
+            if (!((__ballot(lsdg_aligned(ad, th, prec)) >> c) & 1ull)) continue;
+            sumdx = PSL_FADD(sumdx, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cs), c)));
+            sumdy = PSL_FADD(sumdy, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sn), c)));
+            if (lane == c) seq = reg_size;
+            live &= ~(1ull << c);
+            ++reg_size;
+            fresh = 0;
+        }
+#endif
         // the round's pixels: queue entries and marks, one store instruction each
         const unsigned long long acc_round = __ballot(seq >= (first ? 0 : rs0));
         if (seq >= (first ? 0 : rs0)) {

@@ -158,7 +158,7 @@ struct pslfe_line {
         in_pitch = (int)psl_align_up(w, 16);
         in_fstride = psl_align_up((size_t)in_pitch * h, 256);
         PSL_ALLOC(d_in, in_fstride * F);
-        PSL_ALLOC(d_scaled, npx * F * sizeof(double));
+        PSL_ALLOC(d_scaled, npx * std::min<size_t>(F, PSL_LSD_SUBBATCH) * sizeof(double));   // one sub-batch of the f64 working image (run_lsd)
         PSL_ALLOC(d_angdeg, npx * F * sizeof(float));
         PSL_ALLOC(d_modgrad, npx * F * sizeof(double));
         PSL_ALLOC(d_trig, npx * F * sizeof(float2));
@@ -246,25 +246,33 @@ struct pslfe_line {
         hipStream_t st = ctx->stream;
         const unsigned F = (unsigned)nframes;
         {
-            PSL_STAGE_BEGIN(ctx, "line.lsd_scale");
-            const unsigned tx = (P.W + 63) / 64, ty = (P.H + 15) / 16;
-            const int xcd = F >= 8 ? 1 : 0;
-            k_lsd_scale_tiled<<<xcd ? dim3(8, tx * ty, (F + 7) / 8) : dim3(tx, ty, F), 256, 0, st>>>(P, d_gray, stride, frame_stride, d_scaled, (int)F, xcd);
-            PSL_STAGE_END(ctx, "line.lsd_scale");
-        }
-        {
-            PSL_STAGE_BEGIN(ctx, "line.lsd_grad");
+            // LSD steps 1 + 2 in sub-batches of PSL_LSD_SUBBATCH frames: the f64 working image (1.57 MB per frame) only lives between the two kernels, so
+            // d_scaled holds one sub-batch (3.2 GB instead of 19 GB at 12288 frames); 2048 frames x 192 tiles still fill the chip many times over
             PSL_HIP(hipMemsetAsync(d_used, 0, (size_t)P.W * P.H * F, st));  // the `used` map: 1 byte per scaled pixel
             P.singles = F <= PSL_GROW_HELPER_FRAMES;
             P.full_grad = nframes == 1;  // pslfe_line_debug_gradient reads the whole magnitude image of a single-frame call
-            const unsigned gx = (P.W + 63) / 64, gy = (P.H + PSL_GRAD_TH - 1) / PSL_GRAD_TH;
-            const int gxcd = F >= 8 ? 1 : 0;
             const bool ordered = PSL_FRAME_ORDER && F > PSL_GROW_HELPER_FRAMES;   // many-frames launches: k_lsd_grow4 takes the heaviest frames first
             if (ordered) PSL_HIP(hipMemsetAsync(d_weight, 0, (size_t)F * sizeof(int), st));
-            k_lsd_grad<<<gxcd ? dim3(8, gx * gy, (F + 7) / 8) : dim3(gx, gy, F), 256, 0, st>>>(P, d_scaled, d_angdeg, d_modgrad, d_trig, d_seedt, d_used,
-                                                                                                 ordered ? d_weight : nullptr, (int)F, gxcd);
+            const unsigned tx = (P.W + 63) / 64, ty = (P.H + 15) / 16, gy = (P.H + PSL_GRAD_TH - 1) / PSL_GRAD_TH;
+            const size_t npx = (size_t)P.W * P.H;
+            for (unsigned f0 = 0; f0 < F; f0 += PSL_LSD_SUBBATCH) {
+                const unsigned n = std::min<unsigned>(PSL_LSD_SUBBATCH, F - f0);
+                const int xcd = n >= 8 ? 1 : 0;
+                const size_t po = (size_t)f0 * npx;
+                {
+                    PSL_STAGE_BEGIN(ctx, "line.lsd_scale");
+                    k_lsd_scale_tiled<<<xcd ? dim3(8, tx * ty, (n + 7) / 8) : dim3(tx, ty, n), 256, 0, st>>>(P, d_gray + (size_t)f0 * frame_stride, stride, frame_stride,
+                                                                                                             d_scaled, (int)n, xcd);
+                    PSL_STAGE_END(ctx, "line.lsd_scale");
+                }
+                {
+                    PSL_STAGE_BEGIN(ctx, "line.lsd_grad");
+                    k_lsd_grad<<<xcd ? dim3(8, tx * gy, (n + 7) / 8) : dim3(tx, gy, n), 256, 0, st>>>(P, d_scaled, d_angdeg + po, d_modgrad + po, d_trig + po, d_seedt + po,
+                                                                                                      d_used + po, ordered ? d_weight + f0 : nullptr, (int)n, xcd);
+                    PSL_STAGE_END(ctx, "line.lsd_grad");
+                }
+            }
             if (ordered) k_frame_order<<<1, 1024, 0, st>>>(d_weight, (int)F, P.W * P.H, d_order);
-            PSL_STAGE_END(ctx, "line.lsd_grad");
         }
         P.refine = refine;
         {
@@ -445,7 +453,10 @@ int pslfe_line_debug_gradient(pslfe_line* line, int frame, int* W, int* H, doubl
     PSL_HIP(hipStreamSynchronize(line->ctx->stream));
     *W = line->P.W; *H = line->P.H;
     const size_t npx = (size_t)line->P.W * line->P.H;
-    if (scaled) PSL_HIP(hipMemcpy(scaled, line->d_scaled + frame * npx, npx * sizeof(double), hipMemcpyDeviceToHost));
+    if (scaled) {   // the working image is kept for one sub-batch only (run_lsd)
+        PSL_REQUIRE(line->last_nframes <= PSL_LSD_SUBBATCH, PSLFE_E_STATE, "pslfe_line_debug_gradient: the scaled image is kept for launches of at most %d frames", PSL_LSD_SUBBATCH);
+        PSL_HIP(hipMemcpy(scaled, line->d_scaled + frame * npx, npx * sizeof(double), hipMemcpyDeviceToHost));
+    }
     if (angle_deg) PSL_HIP(hipMemcpy(angle_deg, line->d_angdeg + frame * npx, npx * sizeof(float), hipMemcpyDeviceToHost));
     if (modgrad) PSL_HIP(hipMemcpy(modgrad, line->d_modgrad + frame * npx, npx * sizeof(double), hipMemcpyDeviceToHost));
     return PSLFE_OK;
