@@ -451,12 +451,12 @@ def main():
     mg = import_module("psl_slam_amd.multigpu")
 
     # Frames per launch.  12288 = two rounds of the 6144 wave slots of the LSD growing (+3.8 % frames/s over 6144: the launch lasts as long
-    # as its longest frames) when the device's FREE memory holds it: 22.9 MB per frame (pipeline buffers 19.5 + 4.4, gray, depth f32) +
+    # as its longest frames) when the device's FREE memory holds it: 21.7 MB per frame (pipeline buffers 15.8 + 4.4, gray, depth f32: 265 GB in use at 12288) +
     # the gather's buffers (N > 1: two send buffers per rank, ONE receive buffer of world x batch records on rank 0; --host-io: pinned
     # staging is host memory, the u16 depth copy 0.6 MB per frame) + 6 GB of slack.  Every rank takes the same decision (MIN over ranks).
     REC_BYTES = 104 * 1024   # upper estimate of one result record (101 120 B at 1100 keypoint rows / 200 lines / 512 fans / 64 planes)
     def need_bytes(b):
-        n = b * 22.9e6 + 6e9
+        n = b * 21.7e6 + 6e9
         if world > 1 or args.host_io:
             n += 2 * b * REC_BYTES + (world * b * REC_BYTES * (1 if args.gather == "root" else 2) if world > 1 else 0)
         if args.host_io:
