@@ -84,7 +84,8 @@ STAGE_KERNELS = {
     "orb.pyramid": [("k_pyr_resize_tiled", NLEVELS - 1)], "orb.fast": [("k_fast_cells4", 1)], "orb.octree": [("k_octree<256>", 1)],
     "orb.blur": [("k_blur7", 1)], "orb.describe": [("k_orient_describe", 1)],
     "match.grid": [("k_frame_import", 1), ("k_build_grid", 1)], "match.window": [("k_window_eval", 1), ("k_window_resolve<0, 4096, 1024>", 1)],
-    "line.lsd_scale": [("k_lsd_scale_tiled", 1)], "line.lsd_grad": [("k_lsd_grad", 1)], "line.lsd_grow": [("k_lsd_grow4<0>", 1)],
+    "line.lsd_scale": [("k_lsd_scale_tiled", -2048)], "line.lsd_grad": [("k_lsd_grad", -2048)],   # -n: one launch per sub-batch of n frames
+    "line.lsd_grow": [("k_lsd_grow4<0>", 1)],
     "line.nfa_count": [("k_lsd_nfa_count<%d>" % ph, 1) for ph in (-2, -1, 0, 1, 2, 3)],
     "line.nfa_eval": [("k_lsd_nfa_%s<%d>" % (k, ph), 1) for k in ("setup", "series", "select") for ph in (-2, -1, 0, 1, 2, 3)],
     "line.merge": [("k_line_merge<512>", 1), ("k_line_merge<1024>", 1)], "line.lbd_pre": [("k_lbd_pre", 1)], "line.lbd": [("k_lbd", 1)], "line.pair": [("k_lil_pair", 1)],
@@ -107,6 +108,8 @@ def pmc_traffic(workload, stage, batch):
         total = 0.0
         for kern, n in STAGE_KERNELS[stage]:
             k = j["kernels"][kern]
+            if n < 0:
+                n = -(-batch // -n)
             total += n * (k["read_bytes"] + k["write_bytes"])
         return int(total), f"profiles/{j['tag']}_pmc_summary.txt"
     except Exception:
