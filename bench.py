@@ -463,7 +463,7 @@ def main():
         if world > 1 or args.host_io:
             n += 2 * b * REC_BYTES + (world * b * REC_BYTES * (1 if args.gather == "root" else 2) if world > 1 else 0)
         if args.host_io:
-            n += b * W * H * 2
+            n += b * W * H * (2 * 2 + 1)   # two u16 depth slots and the second gray slot
         return n
     if args.batch:
         B = args.batch
@@ -494,10 +494,27 @@ def main():
         depth_d = d8[torch.from_numpy((idx // 32) % len(depth8)).to(dev)].contiguous()
     host_io = None
     if args.host_io:
-        host_io = {"gray": torch.from_numpy(gray256[idx]).pin_memory()}
+        # Host buffers in, host records out, inside the timed region, as a steady-state pipeline: while the kernels of batch n run, the copy stream
+        # brings in batch n + 1 (double-buffered device inputs) and takes out the records of batch n - 1 - the way a host that reads a recording
+        # ahead (pslfe::FramePrefetcher's caller) overlaps its copies.  One H2D and one D2H per step inside the timed region.
+        host_io = {"gray": torch.from_numpy(gray256[idx]).pin_memory(), "cs": torch.cuda.Stream(dev), "n": 0,
+                   "d_gray": [frames_d, torch.empty_like(frames_d)], "ev_in": [torch.cuda.Event(), torch.cuda.Event()], "ev_done": [None, None],
+                   "ev_pack": torch.cuda.Event()}
         if LINES:
             host_io["depth16"] = torch.from_numpy(np.ascontiguousarray(depth8[(idx // 32) % len(depth8)]).view(np.int16)).pin_memory()  # u16 bits
-            host_io["d_depth16"] = torch.empty((B, H, W), dtype=torch.int16, device=dev)
+            host_io["d_depth16"] = [torch.empty((B, H, W), dtype=torch.int16, device=dev) for _ in range(2)]
+
+        def h2d(slot):   # on the copy stream, after the step that last read this slot
+            cs = host_io["cs"]
+            if host_io["ev_done"][slot] is not None:
+                cs.wait_event(host_io["ev_done"][slot])
+            with torch.cuda.stream(cs):
+                host_io["d_gray"][slot].copy_(host_io["gray"], non_blocking=True)
+                if LINES:
+                    host_io["d_depth16"][slot].copy_(host_io["depth16"], non_blocking=True)
+                host_io["ev_in"][slot].record(cs)
+        host_io["h2d"] = h2d
+        h2d(0)
 
     gather = None
     gather_info = None
@@ -507,22 +524,38 @@ def main():
 
     def step():
         n = nB[0]
-        if host_io is not None:   # H2D inside the step; depth arrives as the sensor's u16 and is converted on the device (src/Tracking.cc:230-235)
-            frames_d.copy_(host_io["gray"], non_blocking=True)
+        d_gray = frames_d
+        if host_io is not None:   # depth arrives as the sensor's u16 and is converted on the device (src/Tracking.cc:230-235)
+            slot = host_io["n"] & 1
+            host_io["n"] += 1
+            host_io["h2d"](slot ^ 1)                       # the next batch comes in while this one is computed
+            stream.wait_event(host_io["ev_in"][slot])      # this batch has arrived
+            d_gray = host_io["d_gray"][slot]
             if LINES:
-                host_io["d_depth16"].copy_(host_io["depth16"], non_blocking=True)
-                P._check(P.lib().pslfe_depth_to_float_device(ctx._h, __import__("ctypes").c_void_p(host_io["d_depth16"].data_ptr()),
+                P._check(P.lib().pslfe_depth_to_float_device(ctx._h, __import__("ctypes").c_void_p(host_io["d_depth16"][slot].data_ptr()),
                                                              __import__("ctypes").c_size_t(B * H * W), __import__("ctypes").c_float(1.0 / 5000.0),
                                                              __import__("ctypes").c_void_p(depth_d.data_ptr())), "pslfe_depth_to_float_device")
         if stream_l is not None:
             stream_l.wait_stream(stream)     # the inputs (and the previous step's record pack) are ordered on the main stream
-        pipe.step(frames_d.data_ptr(), depth_d.data_ptr() if LINES else None, n)
+        pipe.step(d_gray.data_ptr(), depth_d.data_ptr() if LINES else None, n)
         if stream_l is not None:
             stream.wait_stream(stream_l)     # join: the step ends when both pipelines have
+        if host_io is not None:
+            ev = torch.cuda.Event()
+            ev.record(stream)
+            host_io["ev_done"][(host_io["n"] - 1) & 1] = ev   # the slot may be overwritten once this step's kernels are through
         if gather is not None and n == B:
+            if rec_host is not None and host_io.get("ev_d2h", [None, None])[gather.k] is not None:
+                stream.wait_event(host_io["ev_d2h"][gather.k])   # the record buffer this pack overwrites has left for the host
             k = gather.submit(pipe.record_sources(mg))
-            if rec_host is not None:   # D2H of this rank's packed records inside the step
-                rec_host.copy_(gather.send[k], non_blocking=True)
+            if rec_host is not None:   # D2H of this rank's packed records on the copy stream, behind the pack
+                host_io["ev_pack"].record(stream)
+                host_io["cs"].wait_event(host_io["ev_pack"])
+                with torch.cuda.stream(host_io["cs"]):
+                    rec_host.copy_(gather.send[k], non_blocking=True)
+                    ev = torch.cuda.Event()
+                    ev.record(host_io["cs"])
+                host_io.setdefault("ev_d2h", [None, None])[k] = ev
 
     for c in pipe.contexts():
         c.profile(True)
@@ -712,7 +745,8 @@ def main():
         achieved = dom_bytes / dom_s / 1e9
         traffic, traffic_src = pmc_traffic(args.workload + ("" if scene in ("sticks", "desk") else "_" + scene), dom, B)
         per_frame = ORB_BYTES_PER_FRAME + MATCH_BYTES_PER_FRAME + (line_bytes if LINES else 0)
-        io = ("host gray + depth(u16) in, host result records out inside the timed region" if args.host_io else "frames resident in HBM")
+        io = ("host gray + depth(u16) in, host result records out inside the timed region (one H2D and one D2H per step on a copy stream: the next batch comes in "
+              "and the previous records go out while a batch is computed)" if args.host_io else "frames resident in HBM")
         scene_txt = {"sticks": "synthetic structure scene at the configured line load ('sticks': non-overlapping high-contrast bars)",
                      "struct": "synthetic structure-notexture-like stream ('struct': overlapping polygons, the scene of rounds 1 - 2)",
                      "desk": "synthetic RGB-D stream (desk-like)"}[scene]
