@@ -159,8 +159,10 @@ typedef struct pslfe_line pslfe_line;  /* == LINEextractor object               
 
 /* == LINEextractor::LINEextractor(numOctaves, scale, nLSDFeature, min_line_length)
  *    add_src/LineExtractor.cpp:6-25; object created once in Tracking (src/Tracking.cc:127).
- *    Only numOctaves == 1 is supported: every reference YAML sets LINEextractor.nLevels: 1 and the
- *    contrib detect() call truncates scale 1.2 to int 1 (add_src/LineExtractor.cpp:336-337). */
+ *    numOctaves must be 1 (PSLFE_E_INVALID otherwise): every reference YAML sets LINEextractor.nLevels: 1, and the
+ *    contrib detect() call truncates scale 1.2 to int 1 (add_src/LineExtractor.cpp:336-337), with which the stock
+ *    LSDDetector's pyramid for numOctaves > 1 is pyrDown(m, m, Size(cols / 1, rows / 1)) - rejected by pyrDown's size
+ *    assertion: the reference's own call throws there, it does not yield lines. */
 int pslfe_line_create(pslfe_ctx* ctx, int numOctaves, float scale, int nLSDFeature, double min_line_length,
                       int max_batch, pslfe_line** out);
 void pslfe_line_destroy(pslfe_line* line);

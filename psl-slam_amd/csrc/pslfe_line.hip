@@ -381,9 +381,15 @@ int pslfe_line_create(pslfe_ctx* ctx, int numOctaves, float scale, int nLSDFeatu
     *out = nullptr;
     PSL_REQUIRE(numOctaves >= 1 && numOctaves <= PSLFE_MAX_LEVELS && nLSDFeature >= 1 && nLSDFeature <= 2048 && max_batch >= 1 && max_batch <= 65535,
                 PSLFE_E_INVALID, "pslfe_line_create: numOctaves %d nLSDFeature %d max_batch %d", numOctaves, nLSDFeature, max_batch);
-    // LINEextractor::operator() calls detect(image, kls, scale, numOctaves) whose `int scale` parameter
-    // truncates 1.2 to 1 and every RGB-D YAML sets LINEextractor.nLevels: 1 (add_src/LineExtractor.cpp:336-337)
-    PSL_REQUIRE(numOctaves == 1, PSLFE_E_INVALID, "pslfe_line_create: only numOctaves == 1 is supported (all reference configurations)");
+    // LINEextractor::operator() calls detect(image, kls, scale, numOctaves) (add_src/LineExtractor.cpp:336-337) whose `int scale` parameter
+    // truncates the float member 1.2 to 1.  With numOctaves > 1 the stock contrib LSDDetector the reference links then builds its pyramid with
+    // pyrDown(m, m, Size(cols / 1, rows / 1)) - a destination of the SOURCE's size, which pyrDown's size assertion (|2 dst - src| <= 2)
+    // rejects with a cv::Exception (opencv_contrib 3.x LSDDetector.cpp: computeGaussianPyramid; the vendored twin, which the reference does not
+    // call, discards that Size through a comma expression: Thirdparty/line_descriptor/src/LSDDetector_custom.cpp:71).  So the reference's own
+    // call cannot produce a result for numOctaves > 1 - every RGB-D YAML sets LINEextractor.nLevels: 1 - and an error here is its behaviour.
+    PSL_REQUIRE(numOctaves == 1, PSLFE_E_INVALID,
+                "pslfe_line_create: numOctaves %d: the reference's LSDDetector::detect(image, kls, (int)1.2f, numOctaves) throws for numOctaves > 1 "
+                "(pyrDown to the source's own size); only numOctaves == 1 yields lines", numOctaves);
     pslfe_line* l = new pslfe_line();
     l->ctx = ctx; l->numOctaves = numOctaves; l->scale = scale; l->nfeatures = nLSDFeature; l->min_line_length = min_line_length;
     l->max_batch = max_batch;
