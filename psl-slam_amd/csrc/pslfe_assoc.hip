@@ -119,17 +119,11 @@ __global__ void k_associate_planes(const float* __restrict__ planes, const doubl
 }
 
 namespace {
-struct DevBuf {  // tiny RAII for the host-pointer entry points
-    std::vector<void*> p;
-    ~DevBuf() { for (void* q : p) hipFree(q); }
+struct DevBuf {  // the host-pointer entry points' device buffers: carved from the context's scratch arena (no hipMalloc / hipFree per call)
+    pslfe_ctx* ctx;
+    explicit DevBuf(pslfe_ctx* c) : ctx(c) {}
     template <typename T>
-    T* up(const T* host, size_t count, hipStream_t st, hipError_t* e) {
-        void* d = nullptr;
-        if (*e == hipSuccess) *e = hipMalloc(&d, count ? count * sizeof(T) : 1);
-        if (*e == hipSuccess && d) p.push_back(d);
-        if (*e == hipSuccess && host && count) *e = hipMemcpyAsync(d, host, count * sizeof(T), hipMemcpyHostToDevice, st);
-        return (T*)d;
-    }
+    T* up(const T* host, size_t count, hipStream_t st, hipError_t* e) { return psl_scratch_up(ctx, host, count, st, e); }
 };
 }  // namespace
 
@@ -146,7 +140,8 @@ int pslfe_line_search_by_geom_appearance(pslfe_ctx* ctx, const PslKeyLine* kl_la
     if (n1 <= 0 || n2 <= 0) return PSLFE_OK;  // mLdesc.empty() -> 0 (:40-43)
     PSL_HIP(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
-    DevBuf B;
+    { const int rc_ = psl_scratch_begin(ctx); if (rc_) return rc_; }
+    DevBuf B(ctx);
     hipError_t e = hipSuccess;
     PslKeyLine* dl = B.up(kl_last, n1, st, &e);
     PslKeyLine* dc = B.up(kl_cur, n2, st, &e);
@@ -180,7 +175,8 @@ int pslfe_line_frame_bf_match(pslfe_ctx* ctx, const uint8_t* desc1, int n1, cons
     PSL_REQUIRE(desc2, PSLFE_E_INVALID, "pslfe_line_frame_bf_match: desc2 is NULL");
     PSL_HIP(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
-    DevBuf B;
+    { const int rc_ = psl_scratch_begin(ctx); if (rc_) return rc_; }
+    DevBuf B(ctx);
     hipError_t e = hipSuccess;
     uint8_t* dd1 = B.up(desc1, (size_t)n1 * 32, st, &e);
     uint8_t* dd2 = B.up(desc2, (size_t)n2 * 32, st, &e);
@@ -207,7 +203,8 @@ int pslfe_associate_planes(pslfe_ctx* ctx, const float* planes, const double* po
     if (nplanes <= 0 || nmap <= 0) return PSLFE_OK;
     PSL_HIP(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
-    DevBuf B;
+    { const int rc_ = psl_scratch_begin(ctx); if (rc_) return rc_; }
+    DevBuf B(ctx);
     hipError_t e = hipSuccess;
     float* dp = B.up(planes, (size_t)nplanes * 4, st, &e);
     double* dq = B.up(points, (size_t)nplanes * 15, st, &e);

@@ -271,8 +271,9 @@ int pslfe_compute_bow(pslfe_vocab* v, const uint8_t* desc, int n, int levelsup, 
     hipStream_t st = v->ctx->stream;
     // one allocation: desc | fword | fnid | bow_id | bow_start | fv_node | fv_start | fv_idx | counters | fweight | bow_val
     const size_t N = (size_t)n, i4 = 4, need = N * 32 + (N * 5 + 2 * (N + 1) + 4) * i4 + 16 + N * 16;
-    uint8_t* base = nullptr;
-    PSL_HIP(hipMalloc((void**)&base, need));
+    { const int rc_ = psl_scratch_begin(v->ctx); if (rc_) return rc_; }
+    uint8_t* base = static_cast<uint8_t*>(psl_scratch(v->ctx, need));   // the context's scratch arena (no hipMalloc / hipFree per call)
+    PSL_REQUIRE(base, PSLFE_E_HIP, "pslfe_compute_bow: out of device memory");
     uint8_t* p = base;
     uint8_t* d_desc = p; p += N * 32;
     int32_t* d_fword = (int32_t*)p; p += N * 4;
@@ -310,7 +311,6 @@ int pslfe_compute_bow(pslfe_vocab* v, const uint8_t* desc, int n, int levelsup, 
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e != hipSuccess) { pslfe_set_error("pslfe_compute_bow: %s", hipGetErrorString(e)); rc = PSLFE_E_HIP; }
     hipStreamSynchronize(st);
-    hipFree(base);
     *nbow = cnt[0]; *nfv = cnt[1];
     return rc;
 }

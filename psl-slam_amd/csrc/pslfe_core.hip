@@ -42,6 +42,38 @@ int pslfe_ctx::resolve_pending() {
     return PSLFE_OK;
 }
 
+int psl_scratch_begin(pslfe_ctx* ctx) {
+    if (!ctx->arena_extra.empty()) {   // the previous call outgrew the arena: its fall-back blocks go, and the arena grows
+        PSL_HIP(hipStreamSynchronize(ctx->stream));
+        for (void* q : ctx->arena_extra) hipFree(q);
+        ctx->arena_extra.clear();
+    }
+    if (ctx->arena_want > ctx->arena_cap) {
+        PSL_HIP(hipStreamSynchronize(ctx->stream));
+        if (ctx->arena) hipFree(ctx->arena);
+        ctx->arena = nullptr; ctx->arena_cap = 0;
+        const size_t want = psl_align_up(ctx->arena_want + ctx->arena_want / 2, 1 << 20);
+        PSL_HIP(hipMalloc((void**)&ctx->arena, want));
+        ctx->arena_cap = want;
+    }
+    ctx->arena_used = 0; ctx->arena_want = 0;
+    return PSLFE_OK;
+}
+
+void* psl_scratch(pslfe_ctx* ctx, size_t bytes) {
+    const size_t b = psl_align_up(bytes ? bytes : 1, 256);
+    ctx->arena_want += b;
+    if (ctx->arena && ctx->arena_used + b <= ctx->arena_cap) {
+        void* p = ctx->arena + ctx->arena_used;
+        ctx->arena_used += b;
+        return p;
+    }
+    void* p = nullptr;
+    if (hipMalloc(&p, b) != hipSuccess) return nullptr;
+    ctx->arena_extra.push_back(p);
+    return p;
+}
+
 extern "C" {
 
 const char* pslfe_version(void) { return "pslfe 0.1 (gfx950)"; }
@@ -95,6 +127,8 @@ void pslfe_ctx_destroy(pslfe_ctx* ctx) {
     if (!ctx) return;
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
+    for (void* q : ctx->arena_extra) hipFree(q);
+    if (ctx->arena) hipFree(ctx->arena);
     if (ctx->aux_stream) hipStreamSynchronize(ctx->aux_stream);
     ctx->resolve_pending();
     if (ctx->ev_fork) hipEventDestroy(ctx->ev_fork);

@@ -49,6 +49,13 @@ struct pslfe_ctx {
     struct Pending { hipEvent_t a, b; std::string stage; };
     std::vector<Pending> pending;
     int cu_count = 0;
+    // Scratch arena of the host-pointer entry points (small per-call device buffers).  hipMalloc / hipFree per call cost ~10 us each and
+    // hipFree waits for EVERY stream of the device - with a look-ahead extraction running on another context's stream (FramePrefetcher) a
+    // tracker call stalled for the whole batch.  The arena only grows (between calls, to the previous call's high-water mark); a request
+    // that does not fit falls back to hipMalloc for that call.
+    char* arena = nullptr;
+    size_t arena_cap = 0, arena_used = 0, arena_want = 0;
+    std::vector<void*> arena_extra;
 
     int stage_begin(const char* name, hipEvent_t* a, hipEvent_t* b, hipStream_t on = nullptr);
     int stage_end(const char* name, hipEvent_t a, hipEvent_t b, hipStream_t on = nullptr);
@@ -84,5 +91,20 @@ struct pslfe_ctx {
     }
 
 static inline size_t psl_align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// start of a call: releases the previous call's fall-back blocks and grows the arena to what that call wanted (calls on a context are serialised)
+int psl_scratch_begin(pslfe_ctx* ctx);
+// `bytes` of device memory valid until the next psl_scratch_begin on this context (256-byte aligned); nullptr on failure
+void* psl_scratch(pslfe_ctx* ctx, size_t bytes);
+template <typename T>
+static inline T* psl_scratch_up(pslfe_ctx* ctx, const T* host, size_t count, hipStream_t st, hipError_t* e) {
+    T* d = nullptr;
+    if (*e == hipSuccess) {
+        d = static_cast<T*>(psl_scratch(ctx, count ? count * sizeof(T) : 1));
+        if (!d) *e = hipErrorOutOfMemory;
+    }
+    if (*e == hipSuccess && host && count) *e = hipMemcpyAsync(d, host, count * sizeof(T), hipMemcpyHostToDevice, st);
+    return d;
+}
 
 #endif

@@ -204,17 +204,11 @@ __global__ __launch_bounds__(64) void k_line_proj_match(LineMatchArgs A) {
 }
 
 namespace {
-struct DevBufs {
-    std::vector<void*> p;
-    ~DevBufs() { for (void* q : p) hipFree(q); }
+struct DevBufs {  // device buffers of the host-pointer entry point: carved from the context's scratch arena
+    pslfe_ctx* ctx;
+    explicit DevBufs(pslfe_ctx* c) : ctx(c) {}
     template <typename T>
-    T* up(const T* host, size_t count, hipStream_t st, hipError_t* e) {
-        void* d = nullptr;
-        if (*e == hipSuccess) *e = hipMalloc(&d, count ? count * sizeof(T) : 1);
-        if (*e == hipSuccess && d) p.push_back(d);
-        if (*e == hipSuccess && host && count) *e = hipMemcpyAsync(d, host, count * sizeof(T), hipMemcpyHostToDevice, st);
-        return (T*)d;
-    }
+    T* up(const T* host, size_t count, hipStream_t st, hipError_t* e) { return psl_scratch_up(ctx, host, count, st, e); }
 };
 }  // namespace
 
@@ -235,7 +229,8 @@ int pslfe_line_search_by_projection(pslfe_ctx* ctx, const PslKeyLine* kls, const
     if (n == 0) return PSLFE_OK;
     PSL_HIP(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
-    DevBufs B;
+    { const int rc_ = psl_scratch_begin(ctx); if (rc_) return rc_; }
+    DevBufs B(ctx);
     hipError_t e = hipSuccess;
     LineMatchArgs A;
     memset(&A, 0, sizeof(A));

@@ -761,8 +761,9 @@ int pslfe_frame_set_rgbd(pslfe_frame* f, int slot, const PslKeyPoint* kps, const
     PSL_HIP(hipSetDevice(f->ctx->device));
     hipStream_t st = f->ctx->stream;
     const size_t o = (size_t)slot * f->cap;
-    float* d_img = nullptr;
-    PSL_HIP(hipMalloc((void**)&d_img, (size_t)height * depth_stride * sizeof(float)));
+    { const int rc_ = psl_scratch_begin(f->ctx); if (rc_) return rc_; }
+    float* d_img = static_cast<float*>(psl_scratch(f->ctx, (size_t)height * depth_stride * sizeof(float)));   // the context's scratch arena: no hipMalloc / hipFree per frame
+    PSL_REQUIRE(d_img, PSLFE_E_HIP, "pslfe_frame_set_rgbd: out of device memory");
     hipError_t e = hipMemcpyAsync(d_img, depth, (size_t)height * depth_stride * sizeof(float), hipMemcpyHostToDevice, st);
     if (e == hipSuccess && n > 0) e = hipMemcpyAsync(f->S.kps + o, kps, (size_t)n * sizeof(PslKeyPoint), hipMemcpyHostToDevice, st);
     if (e == hipSuccess && n > 0) e = hipMemcpyAsync(f->S.desc + o * 32, desc, (size_t)n * 32, hipMemcpyHostToDevice, st);
@@ -774,7 +775,6 @@ int pslfe_frame_set_rgbd(pslfe_frame* f, int slot, const PslKeyPoint* kps, const
     if (e != hipSuccess) { pslfe_set_error("pslfe_frame_set_rgbd: H2D: %s", hipGetErrorString(e)); rc = PSLFE_E_HIP; }
     if (!rc) rc = frame_post_rgbd(f, slot, 1, d_img, width, height, depth_stride, 0, cam);
     hipStreamSynchronize(st);
-    hipFree(d_img);
     return rc;
 }
 

@@ -29,7 +29,8 @@ inline void check(int rc, const char* what) { if (rc != PSLFE_OK) throw Error(rc
 
 class Context {
 public:
-    explicit Context(int device = 0) { check(pslfe_ctx_create(device, &h_), "pslfe_ctx_create"); }
+    explicit Context(int device = 0) : device_(device) { check(pslfe_ctx_create(device, &h_), "pslfe_ctx_create"); }
+    int device() const { return device_; }
     ~Context() { pslfe_ctx_destroy(h_); }
     Context(const Context&) = delete;
     Context& operator=(const Context&) = delete;
@@ -38,6 +39,7 @@ public:
     void synchronize() { check(pslfe_ctx_synchronize(h_), "pslfe_ctx_synchronize"); }
 private:
     pslfe_ctx* h_ = nullptr;
+    int device_ = 0;
 };
 
 class ORBextractor {
@@ -342,20 +344,23 @@ private:
 // == Look-ahead extraction for the Tracking loop.  The reference's caller is a sequential loop over the frames of a recording
 //    (Examples/RGB-D/rgbd_tum.cc:88-130) that constructs one Frame per image (src/Tracking.cc:240 -> src/Frame.cc:133-208); nothing the
 //    Frame constructor computes depends on the pose of an earlier frame, so the extraction of frames t+1 .. t+K can run in ONE batched
-//    launch while frame t is being tracked.  push() stages a frame (gray + CV_32F depth, copied to HBM); pop() hands out the oldest
-//    staged frame's Frame members - when none is ready, the staged frames (up to `lookahead`) go through
+//    launch while frame t is being tracked.  push() stages a frame (gray + CV_32F depth, copied to HBM); a full batch of `lookahead`
+//    frames is launched at once -
 //        pslfe_orb_extract_batch_device, pslfe_line_extract_batch_device, pslfe_line_pair_batch_device,
 //        pslfe_glue_run_batch_device, pslfe_frame_set_from_orb_rgbd, pslfe_record_pack_device
-//    in one go and the packed per-frame records come back in one copy.  Frame k of a batch sits in slot k of grid() until the NEXT
-//    batch is launched, i.e. until the pop() after the batch's last frame: call the matchers for a frame before popping the next one
-//    (as a Tracking thread does).  isLineGood's rand() stream is seeded with 1 + the frame's running index (convention H7), so the
-//    results are those of the one-frame-at-a-time path, bit for bit, whatever the look-ahead.
-//    A live camera pays K - 1 frames of latency for this; a recording pays nothing.
+//    - asynchronously, on one of TWO lanes (each with its own context / stream, extractor objects and frame grid): while the tracker
+//    works through the frames of one lane, the next batch is extracted on the other.  pop() hands out the oldest frame's Frame
+//    members (the packed per-frame records come back in one copy per batch).  A frame's grid slot - grid() after its pop(), or
+//    frame.grid / frame.slot - stays valid until `lookahead` further frames have been popped: call the matchers for a frame before
+//    popping the next one (as a Tracking thread does).  isLineGood's rand() stream is seeded with 1 + the frame's running index
+//    (convention H7), so the results are those of the one-frame-at-a-time path, bit for bit, whatever the look-ahead.
+//    A live camera pays up to 2 K - 1 frames of latency for this; a recording pays nothing.
 class FramePrefetcher {
 public:
     struct Frame {   // the members of ORB_SLAM2::Frame this path fills
-        uint64_t index = 0;   // running index of the frame (push order)
-        int slot = 0;         // its slot in grid(): SearchByProjection(prefetcher.grid(), frame.slot, ...)
+        uint64_t index = 0;          // running index of the frame (push order)
+        int slot = 0;                // its slot in *grid: SearchByProjection(*frame.grid, frame.slot, ...)
+        FrameGrid* grid = nullptr;
         std::vector<PslKeyPoint> mvKeys, mvKeysUn;
         std::vector<uint8_t> mDescriptors;
         std::vector<float> mvDepth, mvuRight;
@@ -368,38 +373,62 @@ public:
 
     FramePrefetcher(Context& ctx, int cols, int rows, int lookahead, int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST,
                     int nLSDFeature, const PslCamera& cam, float pairRadius = 20.0f, float fanThr = 0.78539816339744830962f)
-        : ctx_(ctx), w_(cols), h_(rows), K_(lookahead < 1 ? 1 : lookahead), nlines_(nLSDFeature), cam_(cam), radius_(pairRadius), fanThr_(fanThr),
-          orb_(ctx, nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, K_), lsd_(ctx, 1, 1.2f, (unsigned)nLSDFeature, 0.0, K_),
-          kpCap_(pslfe_orb_max_keypoints(orb_.get(), cols, rows)), grid_(ctx, kpCap_ > 0 ? kpCap_ : 1, K_) {
-        if (kpCap_ < 0) throw Error(kpCap_, "pslfe_orb_max_keypoints");
-        check(pslfe_device_alloc(ctx.get(), (size_t)K_ * w_ * h_, &d_gray_), "pslfe_device_alloc");
-        check(pslfe_device_alloc(ctx.get(), (size_t)K_ * w_ * h_ * sizeof(float), &d_depth_), "pslfe_device_alloc");
-        caps_.kp_cap = kpCap_; caps_.kl_cap = nLSDFeature; caps_.fan_cap = 4096; caps_.plane_cap = 0;
-        check(pslfe_record_layout(&caps_, &lay_), "pslfe_record_layout");
-        check(pslfe_device_alloc(ctx.get(), (size_t)K_ * lay_.bytes, &d_rec_), "pslfe_device_alloc");
-        rec_.resize((size_t)K_ * lay_.bytes);
+        : w_(cols), h_(rows), K_(lookahead < 1 ? 1 : lookahead), cam_(cam), radius_(pairRadius), fanThr_(fanThr) {
+        for (int l = 0; l < 2; ++l) {
+            Lane& L = lane_[l];
+            L.own = new Context(ctx.device());   // a context (= a stream) of its own per lane: the caller's context stays free for the per-frame
+            L.ctx = L.own;                       // calls of the tracker (LSDmatcher, plane association ...) while a lane extracts
+            L.orb = new ORBextractor(*L.ctx, nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, K_);
+            L.lsd = new LINEextractor(*L.ctx, 1, 1.2f, (unsigned)nLSDFeature, 0.0, K_);
+            kpCap_ = pslfe_orb_max_keypoints(L.orb->get(), cols, rows);
+            if (kpCap_ < 0) throw Error(kpCap_, "pslfe_orb_max_keypoints");
+            L.grid = new FrameGrid(*L.ctx, kpCap_ > 0 ? kpCap_ : 1, K_);
+            check(pslfe_device_alloc(L.ctx->get(), (size_t)K_ * w_ * h_, &L.d_gray), "pslfe_device_alloc");
+            check(pslfe_device_alloc(L.ctx->get(), (size_t)K_ * w_ * h_ * sizeof(float), &L.d_depth), "pslfe_device_alloc");
+            caps_.kp_cap = kpCap_; caps_.kl_cap = nLSDFeature; caps_.fan_cap = 4096; caps_.plane_cap = 0;
+            check(pslfe_record_layout(&caps_, &lay_), "pslfe_record_layout");
+            check(pslfe_device_alloc(L.ctx->get(), (size_t)K_ * lay_.bytes, &L.d_rec), "pslfe_device_alloc");
+            L.rec.resize((size_t)K_ * lay_.bytes);
+        }
     }
     ~FramePrefetcher() {
-        pslfe_device_free(ctx_.get(), d_gray_); pslfe_device_free(ctx_.get(), d_depth_); pslfe_device_free(ctx_.get(), d_rec_);
-        delete glue_;
+        for (int l = 0; l < 2; ++l) {
+            Lane& L = lane_[l];
+            if (L.ctx) {
+                pslfe_ctx_synchronize(L.ctx->get());
+                pslfe_device_free(L.ctx->get(), L.d_gray); pslfe_device_free(L.ctx->get(), L.d_depth); pslfe_device_free(L.ctx->get(), L.d_rec);
+            }
+            delete L.glue; delete L.grid; delete L.lsd; delete L.orb; delete L.own;
+        }
     }
     FramePrefetcher(const FramePrefetcher&) = delete;
     FramePrefetcher& operator=(const FramePrefetcher&) = delete;
 
     int lookahead() const { return K_; }
-    size_t staged() const { return (size_t)staged_; }                 // pushed, not yet extracted
-    size_t ready() const { return (size_t)(batch_n_ - batch_next_); }   // extracted, not yet popped
-    FrameGrid& grid() { return grid_; }
-    ORBextractor& orbExtractor() { return orb_; }
-    LINEextractor& lineExtractor() { return lsd_; }
+    // frames pushed and not yet popped / of those, the ones whose extraction has been launched or collected
+    size_t staged() const { return (size_t)(lane_[0].staged + lane_[1].staged - lane_[0].next - lane_[1].next); }
+    size_t ready() const { return (size_t)((lane_[0].collected ? lane_[0].staged - lane_[0].next : 0) + (lane_[1].collected ? lane_[1].staged - lane_[1].next : 0)); }
+    FrameGrid& grid() { return *lane_[last_].grid; }   // of the frame popped last
+    ORBextractor& orbExtractor() { return *lane_[0].orb; }
+    LINEextractor& lineExtractor() { return *lane_[0].lsd; }
 
-    // Stages one frame: gray 8UC1 (`grayStep` bytes per row), depth CV_32F in metres (`depthStep` floats per row).  At most `lookahead`
-    // frames can be staged: returns false (and stages nothing) when the staging area is full or frames of the previous batch are
-    // still waiting to be popped beyond what the slots hold.
+    // true when push() would accept a frame now (a lane is free or being filled)
+    bool canPush() const {
+        const Lane& L = lane_[stage_];
+        return !L.launched || (L.collected && L.next == L.staged);
+    }
+
+    // Stages one frame: gray 8UC1 (`grayStep` bytes per row), depth CV_32F in metres (`depthStep` floats per row); the batch is launched
+    // when `lookahead` frames are staged.  Returns false (and stages nothing) while both lanes hold frames that have not been popped.
     bool push(const uint8_t* gray, int grayStep, const float* depth, int depthStep) {
-        if (!gray || !depth || staged_ >= K_ || ready() > 0) return false;
-        uint8_t* dg = static_cast<uint8_t*>(d_gray_) + (size_t)staged_ * w_ * h_;
-        float* dd = static_cast<float*>(d_depth_) + (size_t)staged_ * w_ * h_;
+        if (!gray || !depth) return false;
+        Lane& L = lane_[stage_];
+        if (L.launched) {
+            if (!(L.collected && L.next == L.staged)) return false;   // still being popped (or not popped at all)
+            L.launched = L.collected = false; L.staged = L.next = 0;   // every frame of this lane has been handed out: it takes the next batch
+        }
+        uint8_t* dg = static_cast<uint8_t*>(L.d_gray) + (size_t)L.staged * w_ * h_;
+        float* dd = static_cast<float*>(L.d_depth) + (size_t)L.staged * w_ * h_;
         if (grayStep != w_) {   // rows with padding: packed on the host first, one copy either way
             tmp8_.resize((size_t)w_ * h_);
             for (int y = 0; y < h_; ++y) memcpy(tmp8_.data() + (size_t)y * w_, gray + (size_t)y * grayStep, (size_t)w_);
@@ -410,48 +439,39 @@ public:
             for (int y = 0; y < h_; ++y) memcpy(tmp32_.data() + (size_t)y * w_, depth + (size_t)y * depthStep, (size_t)w_ * sizeof(float));
             depth = tmp32_.data();
         }
-        check(pslfe_device_upload(ctx_.get(), dg, gray, (size_t)w_ * h_), "pslfe_device_upload");
-        check(pslfe_device_upload(ctx_.get(), dd, depth, (size_t)w_ * h_ * sizeof(float)), "pslfe_device_upload");
-        ++staged_;
+        check(pslfe_device_upload(L.ctx->get(), dg, gray, (size_t)w_ * h_), "pslfe_device_upload");
+        check(pslfe_device_upload(L.ctx->get(), dd, depth, (size_t)w_ * h_ * sizeof(float)), "pslfe_device_upload");
+        if (++L.staged == K_) { launch(stage_); stage_ ^= 1; }
         return true;
     }
 
-    // Extracts every staged frame now (one batched launch).  pop() calls it when nothing is ready.
+    // Launches the extraction of a partly filled batch now (pop() does it when it runs out of launched frames).
     void flush() {
-        if (staged_ == 0 || ready() > 0) return;
-        const int F = staged_;
-        const uint8_t* dg = static_cast<const uint8_t*>(d_gray_);
-        const float* dd = static_cast<const float*>(d_depth_);
-        check(pslfe_orb_extract_batch_device(orb_.get(), dg, F, w_, h_, w_, (size_t)w_ * h_), "pslfe_orb_extract_batch_device");       // ExtractORB
-        check(pslfe_line_extract_batch_device(lsd_.get(), dg, F, w_, h_, w_, (size_t)w_ * h_), "pslfe_line_extract_batch_device");   // ExtractLSD: extractor
-        check(pslfe_line_pair_batch_device(lsd_.get(), radius_, fanThr_), "pslfe_line_pair_batch_device");                              // src/Frame.cc:505
-        PslRecordSources S;
-        memset(&S, 0, sizeof(S));
-        check(pslfe_orb_results_device(orb_.get(), &S.d_kps, &S.d_desc, &S.d_kp_counts, &S.kp_stride), "pslfe_orb_results_device");
-        check(pslfe_line_results_device(lsd_.get(), &S.d_kls, &S.d_ldesc, &S.d_lineEq, &S.d_kl_counts, &S.kl_stride), "pslfe_line_results_device");
-        check(pslfe_line_fans_device(lsd_.get(), &S.d_fans, &S.d_fan_counts, &S.fan_stride), "pslfe_line_fans_device");
-        if (!glue_) glue_ = new FrameGlue(ctx_, S.kl_stride, S.fan_stride, K_);
-        check(pslfe_glue_run_batch_device(glue_->get(), F, S.d_kls, S.kl_stride, S.d_kl_counts, S.d_fans, S.fan_stride, S.d_fan_counts, dd, w_, h_, &cam_,
-                                          (uint32_t)(1u + next_index_)), "pslfe_glue_run_batch_device");                               // isLineGood, fans, planes
-        check(pslfe_frame_set_from_orb_rgbd(grid_.get(), orb_.get(), dd, w_, h_, &cam_), "pslfe_frame_set_from_orb_rgbd");            // Undistort .. AssignFeaturesToGrid
-        check(pslfe_record_pack_device(ctx_.get(), &caps_, &S, F, d_rec_), "pslfe_record_pack_device");
-        check(pslfe_device_download(ctx_.get(), rec_.data(), d_rec_, (size_t)F * lay_.bytes), "pslfe_device_download");
-        batch_n_ = F; batch_next_ = 0; batch_index0_ = next_index_;
-        next_index_ += (uint64_t)F;
-        staged_ = 0;
+        Lane& L = lane_[stage_];
+        if (!L.launched && L.staged > 0) { launch(stage_); stage_ ^= 1; }
     }
 
-    // The oldest frame not handed out yet; false when nothing is staged or ready.
+    // The oldest frame not handed out yet; false when nothing is staged.  Lanes are filled and emptied alternately, so the oldest frame is
+    // always in lane cur_.
     bool pop(Frame& out) {
-        if (ready() == 0) flush();
-        if (ready() == 0) return false;
-        const int k = batch_next_++;
-        const uint8_t* r = rec_.data() + (size_t)k * lay_.bytes;
+        Lane& L = lane_[cur_];
+        if (L.launched && L.collected && L.next == L.staged) return false;   // used up, and nothing has been pushed since
+        if (!L.launched) {                                                   // a partly filled batch: extract it now
+            if (L.staged == 0) return false;
+            launch(cur_);
+            if (stage_ == cur_) stage_ ^= 1;
+        }
+        if (!L.collected) {   // the batch's packed records, one copy (waits for the lane's stream)
+            check(pslfe_device_download(L.ctx->get(), L.rec.data(), L.d_rec, (size_t)L.staged * lay_.bytes), "pslfe_device_download");
+            L.collected = true;
+        }
+        const int k = L.next++;
+        const uint8_t* r = L.rec.data() + (size_t)k * lay_.bytes;
         int32_t hd[8];
         memcpy(hd, r, sizeof(hd));
         const int nkp = hd[0], nkl = hd[2], nfan = hd[4];
         if ((hd[6] & 7) != 0) throw Error(PSLFE_E_CAPACITY, "FramePrefetcher: a frame's results exceed the record capacities");
-        out.index = batch_index0_ + (uint64_t)k; out.slot = k;
+        out.index = L.index0 + (uint64_t)k; out.slot = k; out.grid = L.grid;
         out.mvKeys.resize(nkp); out.mDescriptors.resize((size_t)nkp * 32);
         out.mvKeylinesUn.resize(nkl); out.mLdesc.resize((size_t)nkl * 32); out.mvKeyLineFunctions.resize((size_t)nkl * 3);
         out.fans.resize((size_t)nfan * 4);
@@ -462,29 +482,64 @@ public:
             memcpy(out.mvKeyLineFunctions.data(), r + lay_.off_lineEq, (size_t)nkl * 3 * sizeof(double));
         }
         if (nfan) memcpy(out.fans.data(), r + lay_.off_fans, (size_t)nfan * 4 * sizeof(float));
-        out.glue = glue_->fetch(k, nkl);                                          // mvLines3D, crossings, mvPlanes ...
-        if (nkp) grid_.fetch(k, out.mvKeysUn, out.mvDepth, out.mvuRight, kpCap_);   // mvKeysUn, mvDepth, mvuRight
+        out.glue = L.glue->fetch(k, nkl);                                            // mvLines3D, crossings, mvPlanes ...
+        if (nkp) L.grid->fetch(k, out.mvKeysUn, out.mvDepth, out.mvuRight, kpCap_);   // mvKeysUn, mvDepth, mvuRight
         else { out.mvKeysUn.clear(); out.mvDepth.clear(); out.mvuRight.clear(); }
+        last_ = cur_;
+        if (L.next == L.staged) cur_ ^= 1;   // this lane is used up: the next frame is the other lane's first
         return true;
     }
 
 private:
-    Context& ctx_;
-    int w_, h_, K_, nlines_;
+    struct Lane {
+        Context* own = nullptr;
+        Context* ctx = nullptr;
+        ORBextractor* orb = nullptr;
+        LINEextractor* lsd = nullptr;
+        FrameGrid* grid = nullptr;
+        FrameGlue* glue = nullptr;   // created after the first batch: its row stride is the line extractor's (pslfe_line_results_device)
+        void* d_gray = nullptr; void* d_depth = nullptr; void* d_rec = nullptr;
+        std::vector<uint8_t> rec;
+        int staged = 0, next = 0;            // frames staged in this lane / handed out
+        bool launched = false, collected = false;
+        uint64_t index0 = 0;
+    };
+
+    // every staged frame of the lane through the extractors, asynchronously on the lane's stream
+    void launch(int l) {
+        Lane& L = lane_[l];
+        const int F = L.staged;
+        const uint8_t* dg = static_cast<const uint8_t*>(L.d_gray);
+        const float* dd = static_cast<const float*>(L.d_depth);
+        check(pslfe_orb_extract_batch_device(L.orb->get(), dg, F, w_, h_, w_, (size_t)w_ * h_), "pslfe_orb_extract_batch_device");       // ExtractORB
+        check(pslfe_line_extract_batch_device(L.lsd->get(), dg, F, w_, h_, w_, (size_t)w_ * h_), "pslfe_line_extract_batch_device");   // ExtractLSD: extractor
+        check(pslfe_line_pair_batch_device(L.lsd->get(), radius_, fanThr_), "pslfe_line_pair_batch_device");                              // src/Frame.cc:505
+        PslRecordSources S;
+        memset(&S, 0, sizeof(S));
+        check(pslfe_orb_results_device(L.orb->get(), &S.d_kps, &S.d_desc, &S.d_kp_counts, &S.kp_stride), "pslfe_orb_results_device");
+        check(pslfe_line_results_device(L.lsd->get(), &S.d_kls, &S.d_ldesc, &S.d_lineEq, &S.d_kl_counts, &S.kl_stride), "pslfe_line_results_device");
+        check(pslfe_line_fans_device(L.lsd->get(), &S.d_fans, &S.d_fan_counts, &S.fan_stride), "pslfe_line_fans_device");
+        if (!L.glue) L.glue = new FrameGlue(*L.ctx, S.kl_stride, S.fan_stride, K_);
+        check(pslfe_glue_run_batch_device(L.glue->get(), F, S.d_kls, S.kl_stride, S.d_kl_counts, S.d_fans, S.fan_stride, S.d_fan_counts, dd, w_, h_, &cam_,
+                                          (uint32_t)(1u + next_index_)), "pslfe_glue_run_batch_device");                               // isLineGood, fans, planes
+        check(pslfe_frame_set_from_orb_rgbd(L.grid->get(), L.orb->get(), dd, w_, h_, &cam_), "pslfe_frame_set_from_orb_rgbd");          // Undistort .. AssignFeaturesToGrid
+        check(pslfe_record_pack_device(L.ctx->get(), &caps_, &S, F, L.d_rec), "pslfe_record_pack_device");
+        L.index0 = next_index_;
+        next_index_ += (uint64_t)F;
+        L.launched = true; L.collected = false; L.next = 0;
+    }
+
+    int w_, h_, K_;
     PslCamera cam_;
     float radius_, fanThr_;
-    ORBextractor orb_;
-    LINEextractor lsd_;
-    int kpCap_;
-    FrameGrid grid_;
-    FrameGlue* glue_ = nullptr;   // created after the first batch: its row stride is the line extractor's (pslfe_line_results_device)
-    void* d_gray_ = nullptr; void* d_depth_ = nullptr; void* d_rec_ = nullptr;
+    int kpCap_ = 0;
+    Lane lane_[2];
     PslRecordCaps caps_;
     PslRecordLayout lay_;
-    std::vector<uint8_t> rec_, tmp8_;
+    std::vector<uint8_t> tmp8_;
     std::vector<float> tmp32_;
-    int staged_ = 0, batch_n_ = 0, batch_next_ = 0;
-    uint64_t next_index_ = 0, batch_index0_ = 0;
+    int stage_ = 0, cur_ = 0, last_ = 0;   // the lane being filled / popped from next / of the frame popped last
+    uint64_t next_index_ = 0;
 };
 
 // DBoW2 ORBVocabulary as far as Frame::ComputeBoW needs it (src/Frame.cc:1053-1060): the tree as flat arrays, transform on the device.

@@ -71,12 +71,12 @@ int main(int argc, char** argv) {
         pslfe::FrameGrid grid1(ctx, cap, 2);
         pslfe::FrameGlue glue(ctx, 2048, 4096);
         pslfe::FramePrefetcher* pf = lookahead > 1 ? new pslfe::FramePrefetcher(ctx, w, h, lookahead, nfeatures, 1.2f, 8, 20, 7, nlines, cam) : nullptr;
-        pslfe::FrameGrid& grid = pf ? pf->grid() : grid1;
+        pslfe::FrameGrid* gridp = &grid1;   // with a look-ahead: the grid of the lane the current frame was extracted on (cur.grid)
         pslfe::ORBmatcher matcher(0.9f, true);
         pslfe::LSDmatcher lmatcher(ctx);
         const std::vector<float> scale = orb.GetScaleFactors();
         float bounds[4];
-        grid.imageBounds(cam, w, h, bounds);  // ComputeImageBounds, first frame only (src/Frame.cc:158-174)
+        grid1.imageBounds(cam, w, h, bounds);  // ComputeImageBounds, first frame only (src/Frame.cc:158-174)
         int next_push = 0;
 
         std::map<std::string, std::vector<double>> T;  // per-call times of the timed frames
@@ -103,11 +103,12 @@ int main(int argc, char** argv) {
             auto t0 = tf;
             int slot = t & 1;
             if (pf) {   // look-ahead: the reader is up to K frames ahead of the tracker; the Frame members come out of the prefetcher
-                if (pf->ready() == 0)
-                    while (next_push < n && pf->push(gray.data() + (size_t)next_push * w * h, w, depth.data() + (size_t)next_push * w * h, w)) ++next_push;
+                // the reader runs ahead for as long as a lane is free (two batches of K frames at most)
+                while (next_push < n && pf->push(gray.data() + (size_t)next_push * w * h, w, depth.data() + (size_t)next_push * w * h, w)) ++next_push;
                 lap("FramePrefetcher push (H2D)", t0);
                 if (!pf->pop(cur)) { fprintf(stderr, "dropin_main: the prefetcher ran dry at frame %d\n", t); return 1; }
                 slot = cur.slot;
+                gridp = cur.grid;
                 lap("FramePrefetcher pop", t0);
             } else {
             orb(img, w, h, w, cur.mvKeys, cur.mDescriptors);                                   // ExtractORB
@@ -124,8 +125,8 @@ int main(int argc, char** argv) {
             cur.glue = glue.run(cur.mvKeylinesUn, cur.fans, dep, w, h, w, cam, 1u + (uint32_t)t);  // isLineGood, fans, planes
             lap("isLineGood+fans+planes", t0);
             if (!cur.mvKeys.empty()) {                                                         // UndistortKeyPoints .. AssignFeaturesToGrid
-                grid.setRGBD(t & 1, cur.mvKeys, cur.mDescriptors, dep, w, h, w, cam);
-                grid.fetch(t & 1, cur.mvKeysUn, cur.mvDepth, cur.mvuRight, cap);
+                grid1.setRGBD(t & 1, cur.mvKeys, cur.mDescriptors, dep, w, h, w, cam);
+                grid1.fetch(t & 1, cur.mvKeysUn, cur.mvDepth, cur.mvuRight, cap);
             }
             lap("Undistort+StereoFromRGBD+Grid", t0);
             }
@@ -149,7 +150,7 @@ int main(int argc, char** argv) {
                         q[i].angle = k.angle; q[i].blocks = 1;
                     }
                     assigned.assign(cur.mvKeys.size(), -1);
-                    return matcher.SearchByProjection(grid, slot, q, last.mDescriptors, nullptr, match, &assigned);
+                    return matcher.SearchByProjection(*gridp, slot, q, last.mDescriptors, nullptr, match, &assigned);
                 };
                 nmatches = project(15);
                 lap("SearchByProjection(cur,last)", t0);
