@@ -158,11 +158,11 @@ def test_octree_properties(oracle):
 
 
 def test_octree_scan_formulation_equals_list_formulation():
-    """tools/octree_proto.cpp: the data-parallel formulation used by the HIP kernel, fuzzed against
+    """tests/octree_proto.cpp: the data-parallel formulation used by the HIP kernel, fuzzed against
     the std::list formulation of the oracle."""
     oracle_lib.build()
     exe = "/tmp/psl_octree_proto"
-    subprocess.run(["g++", "-O2", "-std=c++17", os.path.join(ROOT, "tools", "octree_proto.cpp"), "-L" + oracle_lib.ODIR,
+    subprocess.run(["g++", "-O2", "-std=c++17", os.path.join(ROOT, "tests", "octree_proto.cpp"), "-L" + oracle_lib.ODIR,
                     "-lpsl_oracle", "-Wl,-rpath," + oracle_lib.ODIR, "-o", exe], check=True)
     r = subprocess.run([exe, "1500"], capture_output=True, text=True)
     assert r.returncode == 0 and "0 mismatches" in r.stdout, r.stdout
