@@ -233,13 +233,18 @@ struct Lsd {
         if (rec.width < 1.0) rec.width = 1.0;
     }
 
+    long long debug_refine[8] = {0};  // tap (tools/grow_stats.py): regions of min_reg_size or more | refinements entered | their pixels | regrown pixels |
+                                      // reduce_region_radius calls | its radius steps | pixels it visits | pixels of its region2rect calls
     bool reduce_region_radius(std::vector<RegionPoint>& reg, int& reg_size, double reg_angle, double prec, double p, Rect& rec,
                               double density, double density_th) {
+        ++debug_refine[4];
         const double xc = double(reg[0].x), yc = double(reg[0].y);
         const double r1 = dist_sq(xc, yc, rec.x1, rec.y1), r2 = dist_sq(xc, yc, rec.x2, rec.y2);
         double radSq = r1 > r2 ? r1 : r2;
         while (density < density_th) {
             radSq *= 0.75 * 0.75;
+            ++debug_refine[5];
+            debug_refine[6] += reg_size;
             for (int i = 0; i < reg_size; ++i)
                 if (dist_sq(xc, yc, double(reg[i].x), double(reg[i].y)) > radSq) {
                     used[reg[i].x + reg[i].y * W] = 0;
@@ -248,6 +253,7 @@ struct Lsd {
                     --i;
                 }
             if (reg_size < 2) return false;
+            debug_refine[7] += reg_size;
             region2rect(reg, reg_size, reg_angle, prec, p, rec);
             density = double(reg_size) / (dist(rec.x1, rec.y1, rec.x2, rec.y2) * rec.width);
         }
@@ -256,7 +262,10 @@ struct Lsd {
 
     bool refine(std::vector<RegionPoint>& reg, int& reg_size, double reg_angle, double prec, double p, Rect& rec, double density_th) {
         double density = double(reg_size) / (dist(rec.x1, rec.y1, rec.x2, rec.y2) * rec.width);
+        ++debug_refine[0];
         if (density >= density_th) return true;
+        ++debug_refine[1];
+        debug_refine[2] += reg_size;
         const double xc = double(reg[0].x), yc = double(reg[0].y), ang_c = reg[0].angle;
         double sum = 0, s_sum = 0;
         int n = 0;
@@ -272,6 +281,7 @@ struct Lsd {
         const double mean_angle = sum / double(n);
         const double tau = 2.0 * std::sqrt((s_sum - 2.0 * mean_angle * sum) / double(n) + mean_angle * mean_angle);
         region_grow(reg[0].x, reg[0].y, reg, reg_size, reg_angle, tau);
+        debug_refine[3] += reg_size;
         if (reg_size < 2) return false;
         region2rect(reg, reg_size, reg_angle, prec, p, rec);
         density = double(reg_size) / (dist(rec.x1, rec.y1, rec.x2, rec.y2) * rec.width);
@@ -896,6 +906,14 @@ int pso_lsd_growlog(const uint8_t* gray, int w, int h, int stride, int32_t* out,
     const int n = (int)std::min<size_t>(g.size(), (size_t)cap);
     memcpy(out, g.data(), sizeof(int32_t) * (size_t)n);
     return (int)g.size();
+}
+
+// what the refinement of a frame's regions costs (analysis, tools/grow_stats.py): Lsd::debug_refine
+void pso_lsd_refine_stats(const uint8_t* gray, int w, int h, int stride, long long* out) {
+    Lsd lsd;
+    std::vector<float> v;
+    lsd.detect(gray, w, h, stride, v);
+    memcpy(out, lsd.debug_refine, sizeof lsd.debug_refine);
 }
 
 // LSD + contrib wrapper clamp: returns number of segments, lines = x1,y1,x2,y2 floats

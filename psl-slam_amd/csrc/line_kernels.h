@@ -457,6 +457,9 @@ __device__ __forceinline__ double psl_lsd_density(int reg_size, const LsdRect& r
                             // -DPSL_LSD_RING=128 and running tests/test_line_gpu.py (its "band" image reaches a lag of 85)
 #endif
 #define PSL_LSD_HALF (PSL_LSD_RING / 2)
+#ifndef PSL_REDUCE_SERIAL
+#define PSL_REDUCE_SERIAL 0   // 1: reduce_region_radius walked entry by entry as the reference writes it (A/B, tools/ab_build.sh)
+#endif
 
 struct LsdW {
     int W, H, lane;
@@ -848,6 +851,10 @@ __device__ __forceinline__ double lsdw_lane_f64(double v, int lane) {
 }
 
 __device__ void lsdw_region2rect(const LsdW& F, int reg_size, double reg_angle, double prec, LsdRect* rec) {
+#if PSL_GROW_DIAG == 4 || PSL_GROW_DIAG == 5
+  for (int diag_rep = 0; diag_rep < (PSL_GROW_DIAG == 4 ? 2 : 1); ++diag_rep) {
+    asm volatile("" ::: "memory");
+#endif
     double acc = 0;  // lane 0: sum x w, lane 1: sum y w, lane 2: sum w
     for (int base = 0; base < reg_size; base += 64) {
         const int j = base + F.lane, cnt = min(64, reg_size - base);
@@ -909,6 +916,9 @@ __device__ void lsdw_region2rect(const LsdW& F, int reg_size, double reg_angle, 
     rec->width = PSL_DSUB(w_max, w_min);
     if (rec->width < 1.0) rec->width = 1.0;
     rec->theta = theta; rec->dx = dx; rec->dy = dy;  // read by the NFA validation (LSD_REFINE_ADV) only
+#if PSL_GROW_DIAG == 4 || PSL_GROW_DIAG == 5
+  }
+#endif
 }
 
 __device__ int lsdw_refine(const LsdW& F, int reg_size, double reg_angle, double prec, LsdRect* rec, double density_th, LsdgPend& pd, int trip_end,
@@ -921,6 +931,11 @@ __device__ int lsdw_refine(const LsdW& F, int reg_size, double reg_angle, double
     const double ang_c = PSL_DMUL((double)F.ang[x0 + y0 * F.W], PSL_DEG2RAD);
     double acc = 0;  // lane 0: sum of the angle differences, lane 1: sum of their squares (pixels outside the radius stage +0.0)
     int n = 0;
+#if PSL_GROW_DIAG == 5
+  for (int diag_rep = 0; diag_rep < 2; ++diag_rep) {
+    asm volatile("" ::: "memory");
+    acc = 0; n = 0;
+#endif
     for (int base = 0; base < reg_size; base += 64) {
         const int j = base + F.lane, cnt = min(64, reg_size - base);
         double ang_d = 0;
@@ -941,6 +956,9 @@ __device__ int lsdw_refine(const LsdW& F, int reg_size, double reg_angle, double
         acc = lsdw_sum_rows(F, acc, cnt);
         __builtin_amdgcn_wave_barrier();
     }
+#if PSL_GROW_DIAG == 5
+  }
+#endif
     const double sum = lsdw_lane_f64(acc, 0), s_sum = lsdw_lane_f64(acc, 1);
     const double mean_angle = sum / (double)n;
     const double tau = PSL_DMUL(2.0, __dsqrt_rn(PSL_DADD(PSL_DSUB(s_sum, PSL_DMUL(PSL_DMUL(2.0, mean_angle), sum)) / (double)n, PSL_DMUL(mean_angle, mean_angle))));
@@ -949,27 +967,101 @@ __device__ int lsdw_refine(const LsdW& F, int reg_size, double reg_angle, double
     lsdw_region2rect(F, reg_size, reg_angle, prec, rec);
     density = psl_lsd_density(reg_size, *rec);
     if (density >= density_th) return reg_size;
-    // reduce_region_radius: rare; the swap-with-last compaction defines the later summation order, so it
-    // runs as written (uniform scalar code, lane 0 stores; the queue is re-mirrored into the ring afterwards)
+    // reduce_region_radius.  The reference walks the region's list once per radius step and removes a pixel outside the radius by
+    // swapping the list's LAST element into its place (and looks at that one next); the order it leaves defines the order of the later
+    // sums, so it has to be reproduced - but not by walking: with m = the pixels that stay, every stayer in front of position m keeps
+    // its place, and the k-th hole in front of m (ascending) receives the k-th stayer found behind m going DOWN from the end (the
+    // elements the walk swaps to the front and removes right away are passed over by that descent).  Three coalesced passes per radius
+    // step instead of one dependent memory round trip per listed pixel: count and release | stayers behind m, ranked from the end, to a
+    // scratch list behind the queue | holes in front of m filled by rank.  Dense scenes spend most of the chain here if it is walked
+    // (12288 frames of the 'sticks' scene: 80 k list entries walked per frame, k_lsd_grow4 211 ms; profiles/r03q_grow_parts.log).
+    // A step that removes nothing leaves rectangle and density as they are: no region2rect for it.
     const double d1 = psl_dist_sq(xc, yc, rec->x1, rec->y1), d2 = psl_dist_sq(xc, yc, rec->x2, rec->y2);
     double radSq = d1 > d2 ? d1 : d2;
     for (int j = F.lane; j < reg_size; j += 64) F.reg[j] = lsdw_reg(F, j, reg_size);  // make HBM copy authoritative
     __builtin_amdgcn_wave_barrier();
+    const unsigned long long lt = (1ull << F.lane) - 1ull;
     while (density < density_th) {
         radSq = PSL_DMUL(radSq, 0.75 * 0.75);
-        for (int i = 0; i < reg_size; ++i) {
-            const uint32_t rp = F.reg[i];
-            const int px = (int)(rp & 0xffff), py = (int)(rp >> 16);
-            if (psl_dist_sq(xc, yc, (double)px, (double)py) > radSq) {
-                const int a = px + py * F.W;
-                const uint32_t last = F.reg[reg_size - 1];
-                if (F.lane == 0) {
-                    lsdg_mark(F, a, 0);
-                    F.reg[i] = last; F.reg[reg_size - 1] = rp;
+        const int n = reg_size;
+#if !PSL_REDUCE_SERIAL
+        int m = 0;
+#if PSL_GROW_DIAG == 5
+      for (int diag_rep = 0; diag_rep < 2; ++diag_rep) {
+        asm volatile("" ::: "memory");
+        m = 0;
+#endif
+        for (int base = 0; base < n; base += 64) {
+            const int j = base + F.lane;
+            bool in = false;
+            if (j < n) {
+                const uint32_t rp = F.reg[j];
+                const int px = (int)(rp & 0xffff), py = (int)(rp >> 16);
+                in = !(psl_dist_sq(xc, yc, (double)px, (double)py) > radSq);
+                if (!in) lsdg_mark(F, px + py * F.W, 0);
+            }
+            m += __popcll(__ballot(in));
+        }
+#if PSL_GROW_DIAG == 5
+      }
+#endif
+        if (m == n) continue;
+        if (m >= 2 && (size_t)n + (size_t)(n - m) <= (size_t)F.W * F.H) {
+            uint32_t* S = F.reg + n;   // scratch: the stayers behind m, last first (at most n - m of them)
+            int fr = 0;
+#if PSL_GROW_DIAG == 5
+          for (int diag_rep = 0; diag_rep < 2; ++diag_rep) {
+            asm volatile("" ::: "memory");
+            fr = 0;
+#endif
+            for (int e = n; e > m; e -= 64) {
+                const int q = e - 1 - F.lane;
+                bool in = false;
+                uint32_t rp = 0;
+                if (q >= m) {
+                    rp = F.reg[q];
+                    in = !(psl_dist_sq(xc, yc, (double)(int)(rp & 0xffff), (double)(int)(rp >> 16)) > radSq);
                 }
-                __builtin_amdgcn_wave_barrier();
-                --reg_size;
-                --i;
+                const unsigned long long b = __ballot(in);
+                if (in) S[fr + __popcll(b & lt)] = rp;
+                fr += __popcll(b);
+            }
+#if PSL_GROW_DIAG == 5
+          }
+#endif
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            int hr = 0;
+            for (int base = 0; base < m; base += 64) {
+                const int j = base + F.lane;
+                bool out = false;
+                if (j < m) {
+                    const uint32_t rp = F.reg[j];
+                    out = psl_dist_sq(xc, yc, (double)(int)(rp & 0xffff), (double)(int)(rp >> 16)) > radSq;
+                }
+                const unsigned long long b = __ballot(out);
+                if (out) F.reg[j] = S[hr + __popcll(b & lt)];
+                hr += __popcll(b);
+            }
+            reg_size = m;
+        } else if (m < 2) {
+            reg_size = m;   // (the marks are released; what the list holds no longer matters)
+        } else
+#endif
+        {   // the walk as written (no room for the scratch list behind a queue of more than two thirds of the image; or -DPSL_REDUCE_SERIAL=1)
+            for (int i = 0; i < reg_size; ++i) {
+                const uint32_t rp = F.reg[i];
+                const int px = (int)(rp & 0xffff), py = (int)(rp >> 16);
+                if (psl_dist_sq(xc, yc, (double)px, (double)py) > radSq) {
+                    const int a = px + py * F.W;
+                    const uint32_t last = F.reg[reg_size - 1];
+                    if (F.lane == 0) {
+                        lsdg_mark(F, a, 0);
+                        F.reg[i] = last; F.reg[reg_size - 1] = rp;
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    --reg_size;
+                    --i;
+                }
             }
         }
         if (reg_size < 2) {
@@ -977,6 +1069,7 @@ __device__ int lsdw_refine(const LsdW& F, int reg_size, double reg_angle, double
             pd.PA = 0ull;
             return 0;
         }
+        __builtin_amdgcn_wave_barrier();
         for (int j = F.lane; j < min(reg_size, PSL_LSD_RING); j += 64) {  // ring must mirror the last RING entries
             const int idx = reg_size - 1 - j;
             F.ring[idx & (PSL_LSD_RING - 1)] = F.reg[idx];
@@ -1007,6 +1100,9 @@ __device__ __forceinline__ void psl_lsd_store_segment(const LineParams& P, doubl
     out[0] = e[0]; out[1] = e[1]; out[2] = e[2]; out[3] = e[3];
 }
 
+#ifndef PSL_GROW_DIAG
+#define PSL_GROW_DIAG 0
+#endif
 #ifndef PSL_GROW_WAVES
 #define PSL_GROW_WAVES 8   // waves per SIMD.  Round 2 (1024-entry ring, 12288 struct frames, tools/occ_sweep.sh): 5: 60.5 ms, 6: 52.1 ms, 7: 53.4 ms - but 5.9 KB of
                            // LDS per wave capped the CU at 27 waves, so 7 and 8 never ran.  Round 3, 512-entry ring (3.8 KB per wave, 32 waves per CU), 12288 frames of
@@ -1131,7 +1227,12 @@ __global__ __launch_bounds__(64 * (1 + HELPERS), HELPERS ? 1 : PSL_GROW_WAVES) v
                 mask &= mask - 1;
                 int x = trip_x + q * 64 + s, y = trip_y;
                 while (x >= P.W) { x -= P.W; ++y; }
+#if PSL_GROW_DIAG == 3   // diagnostic timing builds only (tools/ab_round3e.sh): 3 = no growth at all (every seed a singleton), 1 = no rectangle / refinement, 2 = no refinement;
+                         // 4 = every region2rect twice, 5 = the refinement's statistics loop and the count / scratch passes of its radius steps twice (same results: their cost = the time added)
+                if (true) {
+#else
                 if ((smq >> s) & 1ull) {
+#endif
                     // a static singleton: the region it would grow is itself.  Its mark joins the pending ones if it lies in their window;
                     // otherwise those are waited for and it opens a window of its own.
                     const int dxp = x - pd.pox, dyp = y - pd.poy;
@@ -1149,9 +1250,16 @@ __global__ __launch_bounds__(64 * (1 + HELPERS), HELPERS ? 1 : PSL_GROW_WAVES) v
                 int reg_size = lsdg_region_grow4(F, x, y, &reg_angle, P.prec, fcP, pd, false, trip_end, touched);
                 if (touched) { stale = true; dirty = true; }
                 if (reg_size < P.min_reg_size) continue;
+#if PSL_GROW_DIAG == 1
+                continue;
+#endif
                 LsdRect rec;
                 lsdw_region2rect(F, reg_size, reg_angle, P.prec, &rec);
+#if PSL_GROW_DIAG == 2
+                const int kept = reg_size;
+#else
                 const int kept = lsdw_refine(F, reg_size, reg_angle, P.prec, &rec, 0.7, pd, trip_end, touched);
+#endif
                 if (touched) { stale = true; dirty = true; }
                 if (!kept) continue;
                 if (count < P.maxseg && lane == 0) {

@@ -269,11 +269,12 @@ def _assert_extract_equal(got, ref, what):
 
 @pytest.mark.parametrize("refine_mode", [ADV, STD], indirect=True)
 @pytest.mark.parametrize("style,seed,t", [("struct", 3, 0), ("desk", 4, 0), ("struct", 8, 0), ("struct", 5, 0), ("desk", 7, 7), ("struct", 9, 15),
-                                          ("desk", 11, 23)])
+                                          ("desk", 11, 23), ("sticks", 13, 0), ("sticks", 14, 5)])
 def test_full_line_extractor(style, seed, t, refine_mode):
     """LINEextractor::operator() bit for bit: keylines (all 17 fields), LBD descriptors, line equations.  struct/5 t=0 is the
-    frame of round 1's stress-run mismatch (one LBD row, |dx| 1.2e-4, before atanf was restated); the last three are frames of
-    that stress set."""
+    frame of round 1's stress-run mismatch (one LBD row, |dx| 1.2e-4, before atanf was restated); the next three are frames of
+    that stress set; 'sticks' is the dense scene of the headline bench: ~220 refinements and ~150 reduce_region_radius calls with
+    ~580 radius steps per frame (the compaction by rank of lsdw_refine; 'desk' has ~120 calls, 'struct' ~10)."""
     import oracle_lib
     img = _scene(style, seed, t)
     ref = oracle_lib.line_extract(img, 200)
