@@ -527,7 +527,12 @@ __device__ __forceinline__ unsigned long long lsdg_uniform64(unsigned long long 
     const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
     return ((unsigned long long)hi << 32) | lo;
 }
-struct LsdgFast { float t_hi, t_lo; int ok; };
+struct LsdgFast { float t_hi, t_lo; int ok; unsigned long long th2; };
+__device__ __forceinline__ unsigned long long lsdg_pack2(float lo, float hi) {
+    return ((unsigned long long)__float_as_uint(hi) << 32) | (unsigned long long)__float_as_uint(lo);
+}
+__device__ __forceinline__ float lsdg_lo(unsigned long long v) { return __uint_as_float((uint32_t)v); }
+__device__ __forceinline__ float lsdg_hi(unsigned long long v) { return __uint_as_float((uint32_t)(v >> 32)); }
 __device__ __forceinline__ LsdgFast lsdg_fast_setup(double prec) {
     LsdgFast f;
     const float p = (float)prec;
@@ -535,6 +540,9 @@ __device__ __forceinline__ LsdgFast lsdg_fast_setup(double prec) {
     // cr < t_hi max(dot, 0) => joins, cr >= t_lo max(dot, 0) => does not; -1 / +inf: never true (inf * 0 = NaN compares false)
     f.t_hi = f.ok && p - PSL_G4_MARGIN > 0.f ? psl_tanf(p - PSL_G4_MARGIN) * (1.f - 1e-5f) : -1.f;
     f.t_lo = f.ok ? psl_tanf(p + PSL_G4_MARGIN) * (1.f + 1e-5f) : __builtin_inff();
+    // lsdg_pops2 compares with t dot instead of t max(dot, 0): |cr| < t_hi dot is false for dot <= 0 as it is (t_hi >= 0), |cr| >= t_lo dot true;
+    // "never": t_hi = 0 (|cr| < +-0 is false), t_lo = NaN (every comparison false)
+    f.th2 = lsdg_pack2(f.t_hi > 0.f ? f.t_hi : 0.f, f.ok ? f.t_lo : __builtin_nanf(""));
     return f;
 }
 // The marks of the last round that ran (of this region or of the one before): possibly still on their way to memory.
@@ -603,7 +611,7 @@ __device__ __forceinline__ int lsdg_decide(unsigned long long& cand, unsigned lo
 }
 
 #ifndef PSL_GROW_ASM_POPS
-#define PSL_GROW_ASM_POPS 1   // 0: the pop loop as compiled C++ around lsdg_decide (A/B, tools/ab_build.sh)
+#define PSL_GROW_ASM_POPS 2   // 2: lsdg_pops2, 1: lsdg_pops, 0: the pop loop as compiled C++ around lsdg_decide (A/B, tools/ab_build.sh)
 #endif
 // lsdg_decide with the loop over the popped entries around it (round 3): per popped entry the compiler spent ~23 scalar instructions on
 // "which lane holds entry i, is it in the window's interior, which of its neighbours are live" (every uniform bool a 64-bit mask, a
@@ -676,6 +684,82 @@ __device__ __forceinline__ int lsdg_pops(unsigned long long& cand, unsigned long
           [sy] "+v"(sumdy), [seq] "+v"(seq), [cx] "=&s"(cx), [c] "=&s"(c), [sa] "=&s"(sa), [sb] "=&s"(sb), [tm] "=&s"(tm), [t0] "=&v"(t0), [t1] "=&v"(t1),
           [t2] "=&v"(t2)
         : [cs] "v"(cs), [sn] "v"(sn), [thi] "v"(t_hi), [tlo] "v"(t_lo), [inter] "s"(interior), [k3] "s"(k3x3)
+        : "scc", "m0", "vcc");
+    return cx;
+}
+
+// lsdg_pops with packed f32 arithmetic and without the `fresh` flag (round 3, second pass; PSL_GROW_ASM_POPS == 2).  The kernel's time is its
+// instruction count (7 waves per SIMD take as long as 8: profiles/r03t_ab_waves.log), and an accepted pixel cost 15 vector + 25 scalar
+// instructions.  Now: the sums live in one register pair S = (sum dx, sum dy), the pixel's vector in U = (cos, sin), the thresholds in
+// TH = (t_hi, t_lo);   (S.x U.x, S.x U.y)  ->  (S.y U.y + S.x U.x, -S.y U.x + S.x U.y) = (dot, cross)  ->  (t_hi dot, t_lo dot)  is three
+// packed instructions, the two compares make five (nine before; max(dot, 0) is not needed: see lsdg_fast_setup), the sums take one
+// packed add.  Whether the masks belong to the current sums is known from the place in the code (two copies of the pop sequence) instead of
+// a flag that is set, reset and tested.  10 vector + ~21 scalar instructions per accepted pixel.  D, PT, U and the pair the accepted
+// vector is read into are bound to registers by name: v_cmp / v_readlane take halves of those pairs, which an operand cannot express.
+// Rounding differs from the three-operation form (one fused step); the decision is only taken outside the margin, which is 2e-3 rad
+// against errors of ~1e-7 |S|.  Re-entry after the caller's exact test recomputes the masks.
+__device__ __forceinline__ int lsdg_pops2(unsigned long long& cand, unsigned long long& live, int& reg_size, int& i, unsigned long long& S, int& seq,
+                                          unsigned long long U, unsigned long long TH, unsigned long long interior) {
+    int cx, c;
+    unsigned long long tm, RA, RN, D, PT, SAB;
+    asm volatile(
+        "s_mov_b32 %[cx], -1\n\t"
+        "s_cmp_lg_u64 %[cand], 0\n\t"
+        "s_cbranch_scc1 .Lcomp%=\n\t"
+        ".LpopS%=:\n\t"                                   // masks not valid
+        "v_cmp_eq_u32 vcc, %[i], %[seq]\n\t"
+        "s_and_b64 %[tm], vcc, %[inter]\n\t"
+        "s_cbranch_scc0 .Lend%=\n\t"
+        "s_ff1_i32_b64 %[c], %[tm]\n\t"
+        "s_add_i32 %[c], %[c], -9\n\t"
+        "s_lshl_b64 %[tm], 0x70707, %[c]\n\t"
+        "s_add_i32 %[i], %[i], 1\n\t"
+        "s_and_b64 %[cand], %[tm], %[live]\n\t"
+        "s_cbranch_scc0 .LpopS%=\n\t"
+        ".Lcomp%=:\n\t"
+        "v_pk_mul_f32 %[PT], %[S], %[U] op_sel:[0,0] op_sel_hi:[0,1]\n\t"
+        "v_pk_fma_f32 %[D], %[S], %[U], %[PT] op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_hi:[1,0,0]\n\t"
+        "v_pk_mul_f32 %[PT], %[TH], %[D] op_sel:[0,0] op_sel_hi:[1,0]\n\t"
+        "v_cmp_lt_f32 %[RA], |v57|, v58\n\t"
+        "v_cmp_ge_f32 %[RN], |v57|, v59\n\t"
+        ".Lhave%=:\n\t"
+        "s_andn2_b64 %[tm], %[cand], %[RN]\n\t"
+        "s_cbranch_scc0 .LpopF%=\n\t"
+        "s_ff1_i32_b64 %[c], %[tm]\n\t"
+        "s_lshl_b64 %[tm], -2, %[c]\n\t"
+        "s_and_b64 %[cand], %[cand], %[tm]\n\t"
+        "s_bitcmp1_b64 %[RA], %[c]\n\t"
+        "s_cbranch_scc0 .Lamb%=\n\t"
+        "s_mov_b32 m0, %[c]\n\t"
+        "v_readlane_b32 s68, v54, %[c]\n\t"
+        "v_readlane_b32 s69, v55, %[c]\n\t"
+        "v_writelane_b32 %[seq], %[rs], m0\n\t"
+        "s_bitset0_b64 %[live], %[c]\n\t"
+        "s_add_i32 %[rs], %[rs], 1\n\t"
+        "s_cmp_lg_u64 %[cand], 0\n\t"
+        "v_pk_add_f32 %[S], %[S], s[68:69]\n\t"
+        "s_cbranch_scc1 .Lcomp%=\n\t"
+        "s_branch .LpopS%=\n\t"
+        ".LpopF%=:\n\t"                                   // masks valid: the last candidates were rejected, the sums have not changed
+        "v_cmp_eq_u32 vcc, %[i], %[seq]\n\t"
+        "s_and_b64 %[tm], vcc, %[inter]\n\t"
+        "s_cbranch_scc0 .Lend%=\n\t"
+        "s_ff1_i32_b64 %[c], %[tm]\n\t"
+        "s_add_i32 %[c], %[c], -9\n\t"
+        "s_lshl_b64 %[tm], 0x70707, %[c]\n\t"
+        "s_add_i32 %[i], %[i], 1\n\t"
+        "s_and_b64 %[cand], %[tm], %[live]\n\t"
+        "s_cbranch_scc0 .LpopF%=\n\t"
+        "s_branch .Lhave%=\n\t"
+        ".Lamb%=:\n\t"
+        "s_mov_b32 %[cx], %[c]\n\t"
+        "s_branch .Ldone%=\n\t"
+        ".Lend%=:\n\t"
+        "s_mov_b64 %[cand], 0\n\t"
+        ".Ldone%=:\n\t"
+        : [cand] "+s"(cand), [live] "+s"(live), [rs] "+s"(reg_size), [i] "+s"(i), [S] "+v"(S), [seq] "+v"(seq), [cx] "=&s"(cx), [c] "=&s"(c), [tm] "=&s"(tm),
+          [RA] "=&s"(RA), [RN] "=&s"(RN), [D] "=&{v[56:57]}"(D), [PT] "=&{v[58:59]}"(PT), [SAB] "=&{s[68:69]}"(SAB)
+        : [U] "{v[54:55]}"(U), [TH] "v"(TH), [inter] "s"(interior)
         : "scc", "m0", "vcc");
     return cx;
 }
@@ -773,6 +857,25 @@ __device__ int lsdg_region_grow4(const LsdW& F, int sx, int sy, double* reg_angl
                 fresh = 0;
             }
         }
+#elif PSL_GROW_ASM_POPS == 2
+        unsigned long long cand = 0ull;
+        unsigned long long S = lsdg_pack2(sumdx, sumdy);
+        const unsigned long long U = lsdg_pack2(cs, sn);
+        for (;;) {
+            const int c = lsdg_pops2(cand, live, reg_size, i, S, seq, U, fc.th2, F.interior);
+            if (c < 0) break;   // no lane of the window's interior holds entry i: the round is over
+            // lane c is within the margin of the threshold: the reference's arithmetic
+            if (rs_angle != reg_size) { reg_deg = psl_fast_atan2(lsdg_hi(S), lsdg_lo(S)); rs_angle = reg_size; }
+            const double ad = PSL_DMUL((double)F.ang[cidx], PSL_DEG2RAD), th = PSL_DMUL((double)reg_deg, PSL_DEG2RAD);
+            if (!((__ballot(lsdg_aligned(ad, th, prec)) >> c) & 1ull)) continue;
+            S = lsdg_pack2(PSL_FADD(lsdg_lo(S), __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cs), c))),
+                           PSL_FADD(lsdg_hi(S), __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sn), c))));
+            if (lane == c) seq = reg_size;
+            live &= ~(1ull << c);
+            ++reg_size;
+        }
+        sumdx = lsdg_lo(S); sumdy = lsdg_hi(S);
+        (void)RA; (void)RN; (void)fresh;
 #else
         unsigned long long cand = 0ull;
         for (;;) {
