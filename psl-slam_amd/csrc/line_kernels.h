@@ -780,15 +780,18 @@ __device__ int lsdg_region_grow4(const LsdW& F, int sx, int sy, double* reg_angl
     const int addr0 = sx + sy * F.W;
     int reg_size = 1;
     const uint32_t xy0 = (uint32_t)sx | ((uint32_t)sy << 16);
-    if (lane == 0) ring[0] = xy0;  // the seed's mark leaves with the marks of the first round (it is lane 11 of that window)
+    if (lane == 0) {   // the seed: queue entry 0 and its mark (issued in front of the first window's load: it has landed when that load returns)
+        ring[0] = xy0;
+        lsdg_mark(F, addr0, 1);
+    }
     float reg_deg = F.ang[addr0];       // these two loads and the first window's are in flight together
     const float2 t0 = F.seedt[addr0];
-    float sumdx = 0.f, sumdy = 0.f;
+    float sumdx = t0.x, sumdy = t0.y;
+    unsigned long long tch = 0ull;
 #ifdef PSL_GROW_STATS
     unsigned gs[16] = {0};
 #endif
     GS(0);
-    bool first = true;
     int rs_angle = 1;  // the region size reg_deg belongs to (the seed's own angle at 1)
     unsigned long long PA = pd.PA;
     int pox = pd.pox, poy = pd.poy;
@@ -808,7 +811,7 @@ __device__ int lsdg_region_grow4(const LsdW& F, int sx, int sy, double* reg_angl
         } else if (qi < reg_size) {
             q = ring[qi & (PSL_LSD_RING - 1)];
         }
-        const uint32_t e = first ? xy0 : (uint32_t)__builtin_amdgcn_readfirstlane((int)q);
+        const uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane((int)q);   // entry i (the first round: the seed, from ring[0])
         const int ox = (int)(e & 0xffff) - 3, oy = (int)(e >> 16) - 1;
         const int x = ox + lx, y = oy + ly;
         const bool inside = (unsigned)x < (unsigned)F.W && (unsigned)y < (unsigned)F.H;
@@ -825,7 +828,6 @@ __device__ int lsdg_region_grow4(const LsdW& F, int sx, int sy, double* reg_angl
         const int px = x - pox, py = y - poy;
         const bool pa = (unsigned)px < 8u && (unsigned)py < 8u && ((PA >> (py * 8 + px)) & 1ull) != 0ull;
         const uint32_t xy = (uint32_t)x | ((uint32_t)y << 16);
-        if (first) { sumdx = t0.x; sumdy = t0.y; }
         const float cs = t.x, sn = t.y;
         // a lane that holds a queue entry is a pixel of the region (the seed among them: its mark is not in memory yet)
         unsigned long long live = __ballot(inside && (cs != 0.f || sn != 0.f) && !ub && !pa && seq < 0);
@@ -894,21 +896,22 @@ __device__ int lsdg_region_grow4(const LsdW& F, int sx, int sy, double* reg_angl
         }
 #endif
         // the round's pixels: queue entries and marks, one store instruction each
-        const unsigned long long acc_round = __ballot(seq >= (first ? 0 : rs0));
-        if (seq >= (first ? 0 : rs0)) {
+        const bool mine = seq >= rs0;
+        const unsigned long long acc_round = __ballot(mine);
+        if (mine) {
             ring[seq & (PSL_LSD_RING - 1)] = xy;
             lsdg_mark(F, cidx, 1);
         }
-        if (__ballot(seq >= rs0 && cidx > addr0 && cidx < trip_end)) touched = true;
-        if (reg_size / PSL_LSD_HALF != rs0 / PSL_LSD_HALF) {  // half a ring of entries is complete: to HBM, long before the ring wraps over it
+        tch |= __ballot(mine && (unsigned)(cidx - addr0 - 1) < (unsigned)(trip_end - addr0 - 1));   // addr0 < cidx < trip_end (the seed lies in its trip)
+        if ((unsigned)reg_size / PSL_LSD_HALF != (unsigned)rs0 / PSL_LSD_HALF) {  // half a ring of entries is complete: to HBM, long before the ring wraps over it
             __builtin_amdgcn_wave_barrier();
-            const int b0 = (reg_size / PSL_LSD_HALF - 1) * PSL_LSD_HALF;
+            const int b0 = (int)((unsigned)reg_size / PSL_LSD_HALF - 1u) * PSL_LSD_HALF;
 #pragma unroll
             for (int k = 0; k < PSL_LSD_HALF / 64; ++k) F.reg[b0 + k * 64 + lane] = ring[(b0 + k * 64 + lane) & (PSL_LSD_RING - 1)];
         }
         PA = acc_round; pox = ox; poy = oy;
-        first = false;
     }
+    if (tch) touched = true;
     pd.PA = PA; pd.pox = pox; pd.poy = poy;
     if (rs_angle != reg_size) reg_deg = psl_fast_atan2(sumdy, sumdx);
 #ifdef PSL_GROW_STATS
@@ -936,13 +939,15 @@ __device__ __forceinline__ double lsdw_wave_min(double v) {
 // staged negated (x - t == x + (-t) in IEEE arithmetic), so the padded sums are bit-identical to the reference's loops.
 typedef __attribute__((address_space(3))) double lds_f64;
 __device__ __forceinline__ double lsdw_sum_rows(const LsdW& F, double acc, int cnt) {
-    const lds_f64* my = (const lds_f64*)F.term + (F.lane < 3 ? F.lane : 0) * 64;
+    typedef double __attribute__((ext_vector_type(2))) f64x2;
+    typedef __attribute__((address_space(3))) f64x2 lds_f64x2;
+    const lds_f64x2* my = (const lds_f64x2*)((const lds_f64*)F.term + (F.lane < 3 ? F.lane : 0) * 64);   // two terms per LDS instruction (s_term is 16-byte aligned)
     for (int t = 0; t < cnt; t += 8) {
-        double v[8];
+        f64x2 v[4];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] = my[t + k];
+        for (int k = 0; k < 4; ++k) v[k] = my[(t >> 1) + k];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) acc = PSL_DADD(acc, v[k]);
+        for (int k = 0; k < 4; ++k) { acc = PSL_DADD(acc, v[k].x); acc = PSL_DADD(acc, v[k].y); }
     }
     return acc;
 }
@@ -1225,7 +1230,7 @@ __global__ __launch_bounds__(64 * (1 + HELPERS), HELPERS ? 1 : PSL_GROW_WAVES) v
                                                    const float2* __restrict__ trig, uint8_t* __restrict__ used, const float2* __restrict__ seedt, uint32_t* __restrict__ reg,
                                                    float* __restrict__ seg, int* __restrict__ nseg, double* __restrict__ rects, int nframes, const int* __restrict__ order) {
     __shared__ uint32_t s_ring[PSL_LSD_RING];
-    __shared__ double s_term[3 * 64];
+    __shared__ __attribute__((aligned(16))) double s_term[3 * 64];
     __shared__ uint32_t s_map[64];
     const int frame = order ? order[blockIdx.x] : (int)blockIdx.x, lane = threadIdx.x;   // many-frames launches: heaviest frames first (k_frame_order)
     const size_t npx = (size_t)P.W * P.H;
