@@ -68,6 +68,18 @@ int main(int argc, char** argv) {
         printf("tanf floats %llu mismatches %llu first 0x%08x\n", (unsigned long long)g_hi - g_lo + 1, bad, first);
         return bad ? 1 : 0;
     }
+    if (!strcmp(argv[1], "ratio")) {   /* psl_ratio_inv(a, b, 1 / b) == a / b for every pair of the table's range */
+        static double inv[PSL_RATIO_BMAX];
+        for (int b = 1; b < PSL_RATIO_BMAX; ++b) inv[b] = 1.0 / (double)b;
+        long bad = 0;
+        for (int b = 1; b < PSL_RATIO_BMAX; ++b)
+            for (int a = 0; a < PSL_RATIO_AMAX; ++a) {
+                const double q = psl_ratio_inv((double)a, (double)b, inv[b]), ref = (double)a / (double)b;
+                if (memcmp(&q, &ref, 8)) { if (bad < 5) printf("a %d b %d: %a vs %a\n", a, b, q, ref); ++bad; }
+            }
+        printf("ratio pairs %ld mismatches %ld\n", (long)(PSL_RATIO_BMAX - 1) * PSL_RATIO_AMAX, bad);
+        return bad ? 1 : 0;
+    }
     if (!strcmp(argv[1], "sincos")) {   /* psl_glibc_sin / psl_glibc_cos must be bit-identical to libm */
         const long n = argc > 2 ? atol(argv[2]) : 20000000;
         const double ranges[3][2] = {{-1.5707963267948966, 1.5707963267948966}, {0.0, 9.5}, {-1000.0, 1000.0}};

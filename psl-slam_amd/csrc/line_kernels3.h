@@ -311,6 +311,7 @@ struct LsdnTables {
     const double* logs;   // [3][PSL_NFA_NP]: log(p_j), log(1 - p_j), log10(p_j) - in HBM, not in the kernel argument: a lane indexes them by its own j
     int lg_n;
     double p0, log_nt;
+    const double* inv;    // [PSL_RATIO_BMAX]: 1 / i, correctly rounded (psl_ratio_inv)
 };
 
 __device__ __forceinline__ double lsdn_lg(const LsdnTables& T, int i) { return i < T.lg_n ? T.lg[i] : lsdn_log_gamma((double)i); }
@@ -669,8 +670,16 @@ __global__ __launch_bounds__(256) void k_lsd_nfa_series(LineParams P, LsdnTables
             // eight terms at once while bin_term >= 1 (i <= (n + 1) / 2: the reference does not test there - 98 % of all terms): the
             // divisions are independent of the running product, only the multiply-add chain is serial
             double bt[8];
+            if (i + 7 < PSL_RATIO_BMAX && n < PSL_RATIO_AMAX) {   // the quotients from the reciprocal table: 3 operations each instead of a division sequence
+                double rv[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) bt[u] = (double)(n - i - u + 1) / (double)(i + u);
+                for (int u = 0; u < 8; ++u) rv[u] = T.inv[i + u];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) bt[u] = psl_ratio_inv((double)(n - i - u + 1), (double)(i + u), rv[u]);
+            } else {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) bt[u] = (double)(n - i - u + 1) / (double)(i + u);
+            }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 term = PSL_DMUL(term, PSL_DMUL(bt[u], p_term));

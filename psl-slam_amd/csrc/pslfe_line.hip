@@ -196,7 +196,8 @@ struct pslfe_line {
             for (int j = 0; j < PSL_NFA_NP; ++j, pj = pj / 2) {
                 lg.push_back(0);  // placeholders, filled below: the three log tables follow the log_gamma table in the same allocation
             }
-            lg.resize((size_t)lgn + 3 * PSL_NFA_NP);
+            lg.resize((size_t)lgn + 3 * PSL_NFA_NP + PSL_RATIO_BMAX);
+            for (int i = 1; i < PSL_RATIO_BMAX; ++i) lg[(size_t)lgn + 3 * PSL_NFA_NP + i] = 1.0 / (double)i;   // psl_ratio_inv's table (k_lsd_nfa_series)
             pj = Q.p;
             for (int j = 0; j < PSL_NFA_NP; ++j, pj = pj / 2) {
                 lg[(size_t)lgn + j] = psl_log(pj); lg[(size_t)lgn + PSL_NFA_NP + j] = psl_log(1.0 - pj); lg[(size_t)lgn + 2 * PSL_NFA_NP + j] = psl_log10(pj);
@@ -204,7 +205,7 @@ struct pslfe_line {
             PSL_ALLOC(d_lgamma, lg.size() * sizeof(double));
             const hipError_t e_ = hipMemcpy(d_lgamma, lg.data(), lg.size() * sizeof(double), hipMemcpyHostToDevice);
             if (e_ != hipSuccess) return fail_prepare(e_, "d_lgamma (upload)");
-            NT.lg = d_lgamma; NT.logs = d_lgamma + lgn; NT.lg_n = lgn; NT.p0 = Q.p; NT.log_nt = Q.log_nt;
+            NT.lg = d_lgamma; NT.logs = d_lgamma + lgn; NT.lg_n = lgn; NT.p0 = Q.p; NT.log_nt = Q.log_nt; NT.inv = d_lgamma + lgn + 3 * PSL_NFA_NP;
         }
         const size_t N = PSL_MERGE_NMAX;
         PSL_ALLOC(M.lines0, F * N * 4 * sizeof(float));

@@ -36,6 +36,14 @@ def test_restated_log_exp_log10_within_one_ulp_of_libm(check_exe):
     print(out.stdout.strip())
 
 
+def test_ratio_from_reciprocal_table_equals_the_division_for_every_pair(check_exe):
+    """k_lsd_nfa_series forms (n - i + 1) / i of nfa()'s binomial tail (OpenCV lsd.cpp nfa(); twin
+    Thirdparty/line_descriptor/src/ED_Lib/NFA.cpp:199-216, which multiplies by a tabulated 1 / i WITHOUT the correction and is therefore
+    not the division) as psl_ratio_inv(a, b, 1 / b): it must be the correctly rounded quotient for all 65536 x 16383 pairs it is used for."""
+    out = subprocess.run([check_exe, "ratio"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "mismatches 0" in out.stdout, out.stdout
+
+
 def test_restated_double_sin_cos_equal_libm(check_exe):
     """MergeTwoLines' double sin / cos of thr in [-pi/2, pi/2] (add_src/uselongline.cpp:320-329) and region2rect's cos / sin of
     theta in [0, 3 pi): glibc's table-driven algorithm restated with a table regenerated from the series
