@@ -199,3 +199,44 @@ def test_cross_dot_test_of_the_window_rounds_never_contradicts_the_reference_dec
             assert not RA.any() and not RN.any()
         sure += int(RA.sum() + RN.sum())
     assert sure > 20000  # the rule decides most cases; the rest goes to the exact path
+
+
+def test_reduce_region_radius_by_rank_equals_the_walk():
+    """lsdw_refine (psl-slam_amd/csrc/line_kernels.h) does not walk the region's list as reduce_region_radius does (OpenCV lsd.cpp; the oracle's
+    Lsd::reduce_region_radius): with m stayers, a stayer in front of position m keeps its place and the k-th hole in front of m receives the k-th stayer
+    behind m counted down from the end.  Both formulations on random lists and stay / leave flags, several radius steps in a row."""
+    import random
+
+    def walk(a, stays):
+        a = list(a); n = len(a); i = 0
+        while i < n:
+            if not stays[a[i]]:
+                a[i], a[n - 1] = a[n - 1], a[i]
+                n -= 1
+                i -= 1
+            i += 1
+        return a[:n]
+
+    def by_rank(a, stays):
+        n = len(a); m = sum(1 for v in a if stays[v])
+        behind = [a[q] for q in range(n - 1, m - 1, -1) if stays[a[q]]]
+        out = list(a[:m]); r = 0
+        for j in range(m):
+            if not stays[a[j]]:
+                out[j] = behind[r]; r += 1
+        assert r == len(behind)
+        return out
+
+    rnd = random.Random(7)
+    for _ in range(30000):
+        n = rnd.randint(1, 90)
+        a = list(range(n)); rnd.shuffle(a)
+        keep = rnd.random()
+        for _step in range(3):   # the list a step leaves is the next step's input
+            stays = [rnd.random() < keep for _ in range(n)]
+            stays[a[0]] = True   # the region's first pixel is the centre of the radius
+            w, r = walk(a, stays), by_rank(a, stays)
+            assert w == r
+            a = w
+            if len(a) < 2:
+                break
