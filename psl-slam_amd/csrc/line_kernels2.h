@@ -729,28 +729,47 @@ __global__ __launch_bounds__(256) void k_lbd(LineParams P, const short2* __restr
         // The gathers of a row do not depend on each other: fetch 8 samples ahead (the coordinate chain is plain
         // float adds), then accumulate them in the reference's order.  One sample per wait made the kernel
         // latency-bound (90 % of the wave cycles in s_waitcnt).
-        for (int w0 = 0; w0 < (int)lengthOfLSP; w0 += 8) {
-            short2 g8[8];
+        // The same values with fewer instructions per sample (the kernel is bound by vector issue, ~55 per sample before): the rounded coordinate
+        // is clamped as an int (v_med3; it is far inside the range of the reference's short), the line's length is wave-uniform (a scalar loop
+        // bound: full blocks of 8 run without a guard), and "if (g > 0) p += g; else n -= g;" is p += max(g, 0); n -= min(g, 0): adding or
+        // subtracting a zero of either sign leaves p and n - which start at +0 and only ever grow - bit for bit as they are.
+        const int len = __builtin_amdgcn_readfirstlane((int)lengthOfLSP);
+        const int iw = (int)imageWidth, ih = (int)imageHeight, rw = (int)realWidth;
+        auto fetch8 = [&](short2* g8) {
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                short t = (short)__builtin_roundf(sCorX);
-                const short xCor = (t < 0) ? 0 : (t > imageWidth) ? imageWidth : t;
-                t = (short)__builtin_roundf(sCorY);
-                const short yCor = (t < 0) ? 0 : (t > imageHeight) ? imageHeight : t;
-                g8[u] = pdxy[(int)yCor * realWidth + xCor];  // coordinates are clamped: reads past the line's end are harmless
+                int t = (int)__builtin_roundf(sCorX);
+                const int xCor = t < 0 ? 0 : (t > iw ? iw : t);
+                t = (int)__builtin_roundf(sCorY);
+                const int yCor = t < 0 ? 0 : (t > ih ? ih : t);
+                g8[u] = pdxy[yCor * rw + xCor];  // coordinates are clamped: reads past the line's end are harmless
                 sCorX = PSL_FADD(sCorX, dL0);
                 sCorY = PSL_FADD(sCorY, dL1);
             }
+        };
+        auto sample = [&](const short2 g) {
+            const float gx = (float)g.x, gy = (float)g.y;
+            const float gDL = PSL_FADD(PSL_FMUL(gx, dL0), PSL_FMUL(gy, dL1));
+            const float gDO = PSL_FADD(PSL_FMUL(gx, dO0), PSL_FMUL(gy, dO1));
+            pL = PSL_FADD(pL, __builtin_fmaxf(gDL, 0.0f)); nL = PSL_FSUB(nL, __builtin_fminf(gDL, 0.0f));
+            pO = PSL_FADD(pO, __builtin_fmaxf(gDO, 0.0f)); nO = PSL_FSUB(nO, __builtin_fminf(gDO, 0.0f));
+        };
+        // The gathers of a row do not depend on each other: fetch 8 samples ahead (the coordinate chain is plain
+        // float adds), then accumulate them in the reference's order.  One sample per wait made the kernel
+        // latency-bound (90 % of the wave cycles in s_waitcnt).
+        int w0 = 0;
+        for (; w0 + 8 <= len; w0 += 8) {
+            short2 g8[8];
+            fetch8(g8);
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                if (w0 + u < (int)lengthOfLSP) {
-                    const float gx = (float)g8[u].x, gy = (float)g8[u].y;
-                    const float gDL = PSL_FADD(PSL_FMUL(gx, dL0), PSL_FMUL(gy, dL1));
-                    const float gDO = PSL_FADD(PSL_FMUL(gx, dO0), PSL_FMUL(gy, dO1));
-                    if (gDL > 0) pL = PSL_FADD(pL, gDL); else nL = PSL_FSUB(nL, gDL);
-                    if (gDO > 0) pO = PSL_FADD(pO, gDO); else nO = PSL_FSUB(nO, gDO);
-                }
-            }
+            for (int u = 0; u < 8; ++u) sample(g8[u]);
+        }
+        if (w0 < len) {
+            short2 g8[8];
+            fetch8(g8);
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (w0 + u < len) sample(g8[u]);
         }
         const float coef = P.gaussG[lane];
         pL = PSL_FMUL(coef, pL); nL = PSL_FMUL(coef, nL); pO = PSL_FMUL(coef, pO); nO = PSL_FMUL(coef, nO);

@@ -90,6 +90,17 @@ __device__ __forceinline__ void lsdn_row_span(const LsdnGeom& G, int y, int W, i
 }
 
 // sums / maxima over aligned groups of GL lanes (GL = 16: four scans per wave)
+// From how many rows on a lane of a scan group takes a whole row (fewer rows: the pixels as slots dealt round-robin / row after row with the lanes
+// sharing it).  Until round 3 both were GL = 16 ("enough rows to occupy the group"): but a row's spans cost ~25 instructions per trial and are paid once per
+// row by the lane that owns it, against once per row and step by every lane of the group - the rectangles of the later phases are small (a few rows of
+// 5 - 20 pixels) and run better with most lanes idle.  12288 dense frames, A/B in one session (profiles/r03z_ab_byrow.log): trials 16: 45.9 ms,
+// 6: 41.3, 3: 40.8; single-geometry scans 16: 45.9, 6: 45.0, 3: 44.9.
+#ifndef PSL_NFA_BYROW_MIN
+#define PSL_NFA_BYROW_MIN 4   // lsdn_count
+#endif
+#ifndef PSL_NFA_BYROW_T
+#define PSL_NFA_BYROW_T 3     // lsdn_count_trials
+#endif
 template <int GL>
 __device__ __forceinline__ int lsdn_group_sum(int v) {
 #pragma unroll
@@ -141,7 +152,7 @@ __device__ __forceinline__ void lsdn_count(const float* __restrict__ ang, int W,
     };
     const int nrows = G.yb - G.ya + 1;
     int tot = 0;
-    if (nrows >= GL) {   // lane = row: the span is computed once per row, four loads of the row in flight
+    if (nrows >= PSL_NFA_BYROW_MIN) {   // lane = row: the span is computed once per row, four loads of the row in flight
         for (int y = G.ya + lane; y <= G.yb; y += GL) {
             int xa, xb;
             lsdn_row_span(G, y, W, &xa, &xb);
@@ -241,7 +252,7 @@ __device__ __forceinline__ void lsdn_count_trials(const float* __restrict__ ang,
     int tot[5], al[5];
 #pragma unroll
     for (int t = 0; t < 5; ++t) { tot[t] = 0; al[t] = 0; }
-    const bool by_row = yb - ya + 1 >= GL;   // lane = row (four loads of the row in flight), or - few, long rows - row after row with the lanes sharing it
+    const bool by_row = yb - ya + 1 >= PSL_NFA_BYROW_T;   // lane = row (four loads of the row in flight), or - few, long rows - row after row with the lanes sharing it
     for (int y = by_row ? ya + lane : ya; y <= yb; y += by_row ? GL : 1) {
         int xa[5], xb[5], ua = 0x7fffffff, ub = -1;
 #pragma unroll
@@ -424,6 +435,7 @@ __device__ __forceinline__ void lsdn_load(const double* __restrict__ r, LsdnRect
 }
 
 #define PSL_NFA_GL 16   // lanes per pixel scan: four (rectangle, trial) scans per wave
+
 template <int PH>
 __global__ __launch_bounds__(256, 4) void k_lsd_nfa_count(LineParams P, const float* __restrict__ angdeg, double* __restrict__ rects,
                                                           const int* __restrict__ nrect, const uint8_t* __restrict__ keep, int2* __restrict__ counts) {
