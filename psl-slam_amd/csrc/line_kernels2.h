@@ -742,7 +742,7 @@ __global__ __launch_bounds__(256) void k_lbd(LineParams P, const short2* __restr
                 const int xCor = t < 0 ? 0 : (t > iw ? iw : t);
                 t = (int)__builtin_roundf(sCorY);
                 const int yCor = t < 0 ? 0 : (t > ih ? ih : t);
-                g8[u] = pdxy[yCor * rw + xCor];  // coordinates are clamped: reads past the line's end are harmless
+                g8[u] = pdxy[(uint32_t)(__mul24(yCor, rw) + xCor)];  // coordinates are clamped: reads past the line's end are harmless (24-bit multiply: a full-rate instruction)
                 sCorX = PSL_FADD(sCorX, dL0);
                 sCorY = PSL_FADD(sCorY, dL1);
             }
