@@ -233,8 +233,8 @@ struct Lsd {
         if (rec.width < 1.0) rec.width = 1.0;
     }
 
-    long long debug_refine[8] = {0};  // tap (tools/grow_stats.py): regions of min_reg_size or more | refinements entered | their pixels | regrown pixels |
-                                      // reduce_region_radius calls | its radius steps | pixels it visits | pixels of its region2rect calls
+    long long debug_refine[10] = {0};  // tap (tools/grow_stats.py): regions of min_reg_size or more | refinements entered | their pixels | regrown pixels |
+                                      // reduce_region_radius calls | its radius steps | pixels it visits | pixels of its region2rect calls | max over the steps of (2 n - m): list length + pixels removed | W * H
     bool reduce_region_radius(std::vector<RegionPoint>& reg, int& reg_size, double reg_angle, double prec, double p, Rect& rec,
                               double density, double density_th) {
         ++debug_refine[4];
@@ -245,6 +245,7 @@ struct Lsd {
             radSq *= 0.75 * 0.75;
             ++debug_refine[5];
             debug_refine[6] += reg_size;
+            const int n0 = reg_size;
             for (int i = 0; i < reg_size; ++i)
                 if (dist_sq(xc, yc, double(reg[i].x), double(reg[i].y)) > radSq) {
                     used[reg[i].x + reg[i].y * W] = 0;
@@ -252,6 +253,8 @@ struct Lsd {
                     --reg_size;
                     --i;
                 }
+            if (n0 + (n0 - reg_size) > debug_refine[8]) debug_refine[8] = n0 + (n0 - reg_size);
+            debug_refine[9] = (long long)W * H;
             if (reg_size < 2) return false;
             debug_refine[7] += reg_size;
             region2rect(reg, reg_size, reg_angle, prec, p, rec);

@@ -198,6 +198,18 @@ def lsd_detect(img, cap=20000):
     return seg[:n].copy()
 
 
+def lsd_refine_stats(img):
+    """Lsd::debug_refine of one frame: regions of min_reg_size or more, refinements entered, their pixels, regrown pixels, reduce_region_radius calls, its
+    radius steps, the list entries it visits, the pixels of its region2rect calls, the largest (list length + pixels removed) of a step, W * H."""
+    L = load()
+    img = np.ascontiguousarray(img)
+    h, w = img.shape
+    out = np.zeros(10, np.int64)
+    L.pso_lsd_refine_stats.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    L.pso_lsd_refine_stats(_p(img), w, h, img.strides[0], _p(out))
+    return out
+
+
 def lsd_gradient(img):
     L = load()
     img = np.ascontiguousarray(img)

@@ -127,6 +127,31 @@ def test_lsd_large_regions_exercise_queue_overflow():
         assert len(ref) >= (4 if mode == STD else 2) and exact
 
 
+def test_lsd_reduce_region_radius_on_a_queue_of_most_of_the_image():
+    """A noisy diagonal ramp on a small image: one region is most of the image and its rectangle, turned by 45 degrees, is twice its size - the
+    density test fails, the refinement regrows it, and reduce_region_radius starts on a list of ~80 % of the pixels.  lsdw_refine's compaction by rank
+    keeps a scratch list behind the queue; here list + removed pixels exceed the image (checked on the oracle's counts), so these steps take the walk that
+    remains for that case, and the later, shorter ones the rank passes - segments bit for bit, both refine modes."""
+    import oracle_lib
+    cases = [(40, 40, 0.3, 0), (40, 40, 0.3, 9), (40, 40, 0.3, 14), (40, 40, 0.45, 5), (40, 40, 0.6, 2), (40, 40, 0.6, 3), (40, 40, 0.8, 6), (36, 36, 0.6, 21), (36, 36, 0.8, 17)]
+    over = steps = 0
+    for w, h, noise, seed in cases:
+        yy, xx = np.mgrid[0:h, 0:w]
+        img = np.clip(254.0 / (w + h - 2) * (xx + yy) + np.random.default_rng(seed).normal(0, noise, (h, w)), 0, 255).astype(np.uint8)
+        st = oracle_lib.lsd_refine_stats(img)
+        over += int(st[8] > st[9])
+        steps += int(st[5])
+        for mode in (ADV, STD):
+            oracle_lib.set_lsd_refine(mode)
+            try:
+                ref = oracle_lib.lsd_detect(img)
+            finally:
+                oracle_lib.set_lsd_refine(ADV)
+            got = _extractor(mode).lsd_detect(img)
+            assert got.shape == ref.shape and (got.view(np.uint32) == ref.view(np.uint32)).all(), (w, h, noise, seed, mode)
+    assert over == len(cases) and steps > 100, (over, steps)
+
+
 def _adversarial_images():
     """Inputs that stress the queue order of the region growing rather than look like a room: rings (regions that turn and close on
     themselves), stripes of every thickness in both diagonals (frontiers several entries wide, growth up and to the left of the seed),
