@@ -629,8 +629,12 @@ __global__ __launch_bounds__(256) void k_lsd_nfa_setup(LineParams P, LsdnTables 
 // other and has the next one loaded before it needs it; a lane whose series has stopped idles until an eighth of its wave is
 // idle - then all such lanes store their sums and start their next entries together.  The hot loop between two such points is
 // the recurrence, the division and the pre-test.
+#ifndef PSL_NFA_SERIES_WAVES
+#define PSL_NFA_SERIES_WAVES 6   // waves per SIMD the register bound allows: the dependent f64 chains leave the vector unit half idle, so more waves help until they spill -
+                                 // without a bound 122 VGPRs (4 waves): nfa_eval 28.8 ms per 12288 dense frames, 5: 27.8, 6 (78 VGPRs): 26.8, 8 (64 + scratch): 41.2 (profiles/r03z_ab_series_waves.log)
+#endif
 template <int PH>
-__global__ __launch_bounds__(256) void k_lsd_nfa_series(LineParams P, LsdnTables T, int nframes, const LsdnSeries* __restrict__ list,
+__global__ __launch_bounds__(256, PSL_NFA_SERIES_WAVES) void k_lsd_nfa_series(LineParams P, LsdnTables T, int nframes, const LsdnSeries* __restrict__ list,
                                                         const int* __restrict__ coff, double2* __restrict__ sstate) {
     __shared__ int s_begin[PSL_NFA_FG], s_pref[PSL_NFA_FG + 1];
     const int cls = blockIdx.x, f0 = (int)blockIdx.y * PSL_NFA_FG, tid = threadIdx.x;
