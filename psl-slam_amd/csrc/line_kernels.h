@@ -488,6 +488,9 @@ __device__ __forceinline__ bool lsdg_used(const LsdW& F, int a) { return lsdg_st
 __device__ __forceinline__ void lsdg_mark(const LsdW& F, int a, uint8_t v) {
     __hip_atomic_store(F.used + a, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
+// pixel index x + y W with a 24-bit multiply (a full-rate instruction; the 64-bit multiply-add the compiler forms for a pointer index is quarter rate): coordinates and W are
+// far below 2^24 / H (the scaled image of a 4096 x 4096 frame would be the limit)
+__device__ __forceinline__ int lsdw_pix(const LsdW& F, int x, int y) { return __mul24(y, F.W) + x; }
 
 // ---------------------------------------------------------------------------------------------
 // Region growing in WINDOW ROUNDS.  The queue order of the reference (breadth first, 3 x 3 neighbours in raster order, the
@@ -815,7 +818,7 @@ __device__ int lsdg_region_grow4(const LsdW& F, int sx, int sy, double* reg_angl
         const int ox = (int)(e & 0xffff) - 3, oy = (int)(e >> 16) - 1;
         const int x = ox + lx, y = oy + ly;
         const bool inside = (unsigned)x < (unsigned)F.W && (unsigned)y < (unsigned)F.H;
-        const int cidx = inside ? x + y * F.W : addr0;
+        const int cidx = inside ? lsdw_pix(F, x, y) : addr0;
         const float2 t = F.trig[cidx];
         const bool ub = lsdg_used(F, cidx);
         // queue entry -> lane of the window (while the load is in flight)
@@ -830,7 +833,7 @@ __device__ int lsdg_region_grow4(const LsdW& F, int sx, int sy, double* reg_angl
         const uint32_t xy = (uint32_t)x | ((uint32_t)y << 16);
         const float cs = t.x, sn = t.y;
         // a lane that holds a queue entry is a pixel of the region (the seed among them: its mark is not in memory yet)
-        unsigned long long live = __ballot(inside && (cs != 0.f || sn != 0.f) && !ub && !pa && seq < 0);
+        unsigned long long live = __ballot((int)inside & ((int)(cs != 0.f) | (int)(sn != 0.f)) & (int)!ub & (int)!pa & (int)(seq < 0));   // (no short circuit: one straight run of compares)
         unsigned long long RA = 0ull, RN = 0ull;  // valid while the sums are the ones they were computed from (`fresh`)
         int fresh = 0;
 #if defined(PSL_GROW_STATS) || !PSL_GROW_ASM_POPS   // the same loop as the compiler writes it (diagnostic counters; A/B)
@@ -970,7 +973,7 @@ __device__ void lsdw_region2rect(const LsdW& F, int reg_size, double reg_angle, 
         if (j < reg_size) {
             const uint32_t rp = lsdw_reg(F, j, reg_size);
             const int px = (int)(rp & 0xffff), py = (int)(rp >> 16);
-            const double w = F.mod[px + py * F.W];
+            const double w = F.mod[(uint32_t)lsdw_pix(F, px, py)];
             t0 = PSL_DMUL((double)px, w); t1 = PSL_DMUL((double)py, w); t2 = w;
         }
         F.term[F.lane] = t0; F.term[64 + F.lane] = t1; F.term[128 + F.lane] = t2;
@@ -988,7 +991,7 @@ __device__ void lsdw_region2rect(const LsdW& F, int reg_size, double reg_angle, 
         if (j < reg_size) {
             const uint32_t rp = lsdw_reg(F, j, reg_size);
             const int px = (int)(rp & 0xffff), py = (int)(rp >> 16);
-            const double w = F.mod[px + py * F.W];
+            const double w = F.mod[(uint32_t)lsdw_pix(F, px, py)];
             const double dx = PSL_DSUB((double)px, x), dy = PSL_DSUB((double)py, y);
             t0 = PSL_DMUL(PSL_DMUL(dy, dy), w); t1 = PSL_DMUL(PSL_DMUL(dx, dx), w);
             t2 = -PSL_DMUL(PSL_DMUL(dx, dy), w);  // Ixy -= dx dy w
@@ -1050,7 +1053,7 @@ __device__ int lsdw_refine(const LsdW& F, int reg_size, double reg_angle, double
         bool in = false;
         if (j < reg_size) {
             const uint32_t rp = lsdw_reg(F, j, reg_size);
-            const int px = (int)(rp & 0xffff), py = (int)(rp >> 16), a = px + py * F.W;
+            const int px = (int)(rp & 0xffff), py = (int)(rp >> 16), a = lsdw_pix(F, px, py);
             lsdg_mark(F, a, 0);
             if (__dsqrt_rn(psl_dist_sq(xc, yc, (double)px, (double)py)) < rec->width) {
                 in = true;
@@ -1106,7 +1109,7 @@ __device__ int lsdw_refine(const LsdW& F, int reg_size, double reg_angle, double
                 const uint32_t rp = F.reg[j];
                 const int px = (int)(rp & 0xffff), py = (int)(rp >> 16);
                 in = !(psl_dist_sq(xc, yc, (double)px, (double)py) > radSq);
-                if (!in) lsdg_mark(F, px + py * F.W, 0);
+                if (!in) lsdg_mark(F, lsdw_pix(F, px, py), 0);
             }
             m += __popcll(__ballot(in));
         }
