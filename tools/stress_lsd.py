@@ -21,7 +21,7 @@ def main():
     ns = int(sys.argv[3]) if len(sys.argv) > 3 else 6
     W, H = 640, 480
     frames = []
-    for style, seed in (("struct", 5), ("desk", 7), ("struct", 9), ("desk", 11)):
+    for style, seed in (("struct", 5), ("desk", 7), ("sticks", 13), ("struct", 9), ("desk", 11), ("sticks", 17)):   # 'sticks': the dense scene of the headline bench
         sc = sf.Scene(W, H, style, seed)
         frames += [sc.gray(t) for t in range(24)]
     frames = np.stack(frames, 0)
