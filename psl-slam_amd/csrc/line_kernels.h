@@ -474,6 +474,7 @@ struct LsdW {
     unsigned long long interior;  // lanes of the 8 x 8 window's 6 x 6 interior
     double* term;     // LDS [3][64]
     uint32_t* reg;    // HBM queue
+    uint32_t* ubits;  // LU variants: the `used` map's "used" bit per pixel, in LDS
 };
 
 __device__ __forceinline__ uint32_t lsdw_reg(const LsdW& F, int idx, int reg_size) {
@@ -481,12 +482,31 @@ __device__ __forceinline__ uint32_t lsdw_reg(const LsdW& F, int idx, int reg_siz
 }
 
 // the `used` map: 0 free, 1 used, 2 free and a static singleton (k_lsd_grad, phase B2)
-__device__ __forceinline__ uint32_t lsdg_state(const LsdW& F, int a) {
-    return __hip_atomic_load(F.used + a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+// LU = 1 (launches of a few frames: one workgroup per frame has the CU's LDS to itself): "used" is a BIT PER PIXEL IN LDS (24 KB at 640x480, 96 KB at
+// 1280x960) on top of the map in memory, which then only carries k_lsd_grad's static-singleton flags and is never written.  Vector-memory operations
+// return in issue order, so with the marks in memory every window load of the chain waited for the mark stores issued in front of it - ~0.8 us per
+// round on an otherwise idle chip, where an L2 hit is ~0.1 us.  With thousands of frames in flight other waves cover that wait (and the bitmaps of 32 frames
+// would not fit a CU's LDS): LU = 0 there.
+typedef __attribute__((address_space(3))) uint32_t lds_ubits;
+template <int LU>
+__device__ __forceinline__ bool lsdg_used(const LsdW& F, int a) {
+    if (LU) return (((lds_ubits*)F.ubits)[a >> 5] >> (a & 31)) & 1u;
+    return __hip_atomic_load(F.used + a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 1u;
 }
-__device__ __forceinline__ bool lsdg_used(const LsdW& F, int a) { return lsdg_state(F, a) == 1u; }
-__device__ __forceinline__ void lsdg_mark(const LsdW& F, int a, uint8_t v) {
-    __hip_atomic_store(F.used + a, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+template <int LU>
+__device__ __forceinline__ uint32_t lsdg_state(const LsdW& F, int a) {
+    const uint32_t g = __hip_atomic_load(F.used + a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (LU) return lsdg_used<1>(F, a) ? 1u : g;
+    return g;
+}
+template <int LU>
+__device__ __forceinline__ void lsdg_mark(const LsdW& F, int a, uint8_t v) {   // v = 1: used, v = 0: released
+    if (LU) {
+        if (v) __hip_atomic_fetch_or((lds_ubits*)F.ubits + (a >> 5), 1u << (a & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        else __hip_atomic_fetch_and((lds_ubits*)F.ubits + (a >> 5), ~(1u << (a & 31)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    } else {
+        __hip_atomic_store(F.used + a, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
 }
 // pixel index x + y W with a 24-bit multiply (a full-rate instruction; the 64-bit multiply-add the compiler forms for a pointer index is quarter rate): coordinates and W are
 // far below 2^24 / H (the scaled image of a 4096 x 4096 frame would be the limit)
@@ -770,6 +790,7 @@ __device__ __forceinline__ int lsdg_pops2(unsigned long long& cand, unsigned lon
 // `regrow`: the refinement's second growth - its releases of the region's pixels must have completed, nothing is pending.
 // `touched`: set when the region took a pixel whose raster index lies in (seed, trip_end): only then has the seed scan to look
 // at the `used` words of its current 256-pixel trip again.
+template <int LU>
 __device__ int lsdg_region_grow4(const LsdW& F, int sx, int sy, double* reg_angle_out, double prec, const LsdgFast fc, LsdgPend& pd,
                                  bool regrow, int trip_end, bool& touched) {
     typedef __attribute__((address_space(3))) uint32_t lds_u32;
@@ -785,7 +806,7 @@ __device__ int lsdg_region_grow4(const LsdW& F, int sx, int sy, double* reg_angl
     const uint32_t xy0 = (uint32_t)sx | ((uint32_t)sy << 16);
     if (lane == 0) {   // the seed: queue entry 0 and its mark (issued in front of the first window's load: it has landed when that load returns)
         ring[0] = xy0;
-        lsdg_mark(F, addr0, 1);
+        lsdg_mark<LU>(F, addr0, 1);
     }
     float reg_deg = F.ang[addr0];       // these two loads and the first window's are in flight together
     const float2 t0 = F.seedt[addr0];
@@ -820,7 +841,7 @@ __device__ int lsdg_region_grow4(const LsdW& F, int sx, int sy, double* reg_angl
         const bool inside = (unsigned)x < (unsigned)F.W && (unsigned)y < (unsigned)F.H;
         const int cidx = inside ? lsdw_pix(F, x, y) : addr0;
         const float2 t = F.trig[cidx];
-        const bool ub = lsdg_used(F, cidx);
+        const bool ub = lsdg_used<LU>(F, cidx);
         // queue entry -> lane of the window (while the load is in flight)
         const int qx = (int)(q & 0xffff) - ox, qy = (int)(q >> 16) - oy;
         map[lane] = 0u;
@@ -829,7 +850,7 @@ __device__ int lsdg_region_grow4(const LsdW& F, int sx, int sy, double* reg_angl
         __builtin_amdgcn_wave_barrier();
         int seq = (int)map[lane] - 1;
         const int px = x - pox, py = y - poy;
-        const bool pa = (unsigned)px < 8u && (unsigned)py < 8u && ((PA >> (py * 8 + px)) & 1ull) != 0ull;
+        const bool pa = LU ? false : ((unsigned)px < 8u && (unsigned)py < 8u && ((PA >> (py * 8 + px)) & 1ull) != 0ull);   // (marks in LDS are never "on their way")
         const uint32_t xy = (uint32_t)x | ((uint32_t)y << 16);
         const float cs = t.x, sn = t.y;
         // a lane that holds a queue entry is a pixel of the region (the seed among them: its mark is not in memory yet)
@@ -903,7 +924,7 @@ __device__ int lsdg_region_grow4(const LsdW& F, int sx, int sy, double* reg_angl
         const unsigned long long acc_round = __ballot(mine);
         if (mine) {
             ring[seq & (PSL_LSD_RING - 1)] = xy;
-            lsdg_mark(F, cidx, 1);
+            lsdg_mark<LU>(F, cidx, 1);
         }
         tch |= __ballot(mine && (unsigned)(cidx - addr0 - 1) < (unsigned)(trip_end - addr0 - 1));   // addr0 < cidx < trip_end (the seed lies in its trip)
         if ((unsigned)reg_size / PSL_LSD_HALF != (unsigned)rs0 / PSL_LSD_HALF) {  // half a ring of entries is complete: to HBM, long before the ring wraps over it
@@ -1032,6 +1053,7 @@ __device__ void lsdw_region2rect(const LsdW& F, int reg_size, double reg_angle, 
 #endif
 }
 
+template <int LU>
 __device__ int lsdw_refine(const LsdW& F, int reg_size, double reg_angle, double prec, LsdRect* rec, double density_th, LsdgPend& pd, int trip_end,
                            bool& touched) {
     double density = psl_lsd_density(reg_size, *rec);
@@ -1054,7 +1076,7 @@ __device__ int lsdw_refine(const LsdW& F, int reg_size, double reg_angle, double
         if (j < reg_size) {
             const uint32_t rp = lsdw_reg(F, j, reg_size);
             const int px = (int)(rp & 0xffff), py = (int)(rp >> 16), a = lsdw_pix(F, px, py);
-            lsdg_mark(F, a, 0);
+            lsdg_mark<LU>(F, a, 0);
             if (__dsqrt_rn(psl_dist_sq(xc, yc, (double)px, (double)py)) < rec->width) {
                 in = true;
                 ang_d = psl_angle_diff_signed(PSL_DMUL((double)F.ang[a], PSL_DEG2RAD), ang_c);
@@ -1073,7 +1095,7 @@ __device__ int lsdw_refine(const LsdW& F, int reg_size, double reg_angle, double
     const double sum = lsdw_lane_f64(acc, 0), s_sum = lsdw_lane_f64(acc, 1);
     const double mean_angle = sum / (double)n;
     const double tau = PSL_DMUL(2.0, __dsqrt_rn(PSL_DADD(PSL_DSUB(s_sum, PSL_DMUL(PSL_DMUL(2.0, mean_angle), sum)) / (double)n, PSL_DMUL(mean_angle, mean_angle))));
-    reg_size = lsdg_region_grow4(F, x0, y0, &reg_angle, tau, lsdg_fast_setup(tau), pd, true, trip_end, touched);
+    reg_size = lsdg_region_grow4<LU>(F, x0, y0, &reg_angle, tau, lsdg_fast_setup(tau), pd, true, trip_end, touched);
     if (reg_size < 2) return 0;
     lsdw_region2rect(F, reg_size, reg_angle, prec, rec);
     density = psl_lsd_density(reg_size, *rec);
@@ -1109,7 +1131,7 @@ __device__ int lsdw_refine(const LsdW& F, int reg_size, double reg_angle, double
                 const uint32_t rp = F.reg[j];
                 const int px = (int)(rp & 0xffff), py = (int)(rp >> 16);
                 in = !(psl_dist_sq(xc, yc, (double)px, (double)py) > radSq);
-                if (!in) lsdg_mark(F, lsdw_pix(F, px, py), 0);
+                if (!in) lsdg_mark<LU>(F, lsdw_pix(F, px, py), 0);
             }
             m += __popcll(__ballot(in));
         }
@@ -1166,7 +1188,7 @@ __device__ int lsdw_refine(const LsdW& F, int reg_size, double reg_angle, double
                     const int a = px + py * F.W;
                     const uint32_t last = F.reg[reg_size - 1];
                     if (F.lane == 0) {
-                        lsdg_mark(F, a, 0);
+                        lsdg_mark<LU>(F, a, 0);
                         F.reg[i] = last; F.reg[reg_size - 1] = rp;
                     }
                     __builtin_amdgcn_wave_barrier();
@@ -1228,7 +1250,7 @@ __device__ __forceinline__ void psl_lsd_store_segment(const LineParams& P, doubl
 // wave 0 publishes in LDS, so that a larger frame (1280x960: 10 MB) keeps a band in front of the scan warm instead of flushing the
 // cache (all of it at once: 25.2 ms against 24.6 ms without helpers).  No effect on results.  Not used with thousands of frames in
 // flight: no L2 to spare and no idle wave slot.  Seed vectors and magnitudes prefetched at defined pixels as well: no further gain.
-template <int HELPERS>
+template <int HELPERS, int LU>
 __global__ __launch_bounds__(64 * (1 + HELPERS), HELPERS ? 1 : PSL_GROW_WAVES) void k_lsd_grow4(LineParams P, const float* __restrict__ angdeg, const double* __restrict__ modgrad,
                                                    const float2* __restrict__ trig, uint8_t* __restrict__ used, const float2* __restrict__ seedt, uint32_t* __restrict__ reg,
                                                    float* __restrict__ seg, int* __restrict__ nseg, double* __restrict__ rects, int nframes, const int* __restrict__ order) {
@@ -1242,16 +1264,20 @@ __global__ __launch_bounds__(64 * (1 + HELPERS), HELPERS ? 1 : PSL_GROW_WAVES) v
     F.W = P.W; F.H = P.H; F.lane = lane;
     F.ang = angdeg + frame * npx; F.mod = modgrad + frame * npx; F.trig = trig + frame * npx; F.used = used + frame * npx; F.reg = reg + frame * npx;
     F.seedt = seedt + frame * npx; F.ring = s_ring; F.term = s_term; F.sctab = P.sctab; F.map = s_map;
+    extern __shared__ uint32_t s_ubits[];   // LU: one "used" bit per scaled pixel (the launch passes 4 * words bytes)
+    F.ubits = LU ? s_ubits : nullptr;
     __shared__ int s_scan_unit;  // HELPERS: the 64-pixel unit the seed scan has reached (written by wave 0, polled by the helpers)
+    static_assert(!LU || HELPERS, "the LDS map needs a workgroup per frame that has the CU to itself");
     if (HELPERS) {
         if (threadIdx.x == 0) s_scan_unit = 0;
+        if (LU) for (int k = threadIdx.x; k < words; k += 64 * (1 + HELPERS)) s_ubits[k] = 0u;
         __syncthreads();
     }
     if (HELPERS && threadIdx.x >= 64) {
         const char* pt = (const char*)F.trig;
         const char* pa = (const char*)F.ang;
         const char* pu = (const char*)F.used;
-        const int units = (int)(npx >> 6);  // 64 pixels: 8 pieces of records, 4 of angles, 1 of the map
+        const int units = (int)(npx >> 6);  // 64 pixels: 8 pieces of records, 4 of angles, 1 of the map (LU: the map in memory is read once per 256-pixel trip of the scan; its piece is still warmed)
         const int ahead = (int)(((size_t)5 << 19) / (64 * 13)) / ((nframes + 7) / 8);  // all helpers of an XCD together stay at most 2.5 MB (of its 4 MB L2) in front of their scans
         // The loads are never waited for individually, so their destination must stay reserved until the final wait: ONE register,
         // read-write operand of every load and consumed after the wait (an output-only operand is free for reuse - as the next
@@ -1299,7 +1325,7 @@ __global__ __launch_bounds__(64 * (1 + HELPERS), HELPERS ? 1 : PSL_GROW_WAVES) v
             for (int q = 0; q < 4; ++q) {
                 const int ad = base + q * 64 + lane;
                 a4[q] = ad < scan_end ? F.ang[ad] : PSL_LSD_NOTDEF;
-                u4[q] = ad < scan_end ? lsdg_state(F, ad) : 1u;
+                u4[q] = ad < scan_end ? lsdg_state<LU>(F, ad) : 1u;
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -1322,14 +1348,14 @@ __global__ __launch_bounds__(64 * (1 + HELPERS), HELPERS ? 1 : PSL_GROW_WAVES) v
             const int ad = base + q * 64 + lane;
             if (stale) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                umq = __ballot(ad < scan_end ? lsdg_used(F, ad) : true);
+                umq = __ballot(ad < scan_end ? lsdg_used<LU>(F, ad) : true);
             }
             unsigned long long mask = dmq & ~umq;
             bool dirty = false;
             while (mask) {
                 if (dirty) {
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    mask &= __ballot(ad < scan_end && !lsdg_used(F, ad));
+                    mask &= __ballot(ad < scan_end && !lsdg_used<LU>(F, ad));
                     dirty = false;
                     if (!mask) break;
                 }
@@ -1346,19 +1372,21 @@ __global__ __launch_bounds__(64 * (1 + HELPERS), HELPERS ? 1 : PSL_GROW_WAVES) v
 #endif
                     // a static singleton: the region it would grow is itself.  Its mark joins the pending ones if it lies in their window;
                     // otherwise those are waited for and it opens a window of its own.
-                    const int dxp = x - pd.pox, dyp = y - pd.poy;
-                    if (pd.PA != 0ull && (unsigned)dxp < 8u && (unsigned)dyp < 8u) {
-                        pd.PA |= 1ull << (dyp * 8 + dxp);
-                    } else {
-                        if (pd.PA != 0ull) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                        pd.PA = 1ull; pd.pox = x; pd.poy = y;
+                    if (!LU) {
+                        const int dxp = x - pd.pox, dyp = y - pd.poy;
+                        if (pd.PA != 0ull && (unsigned)dxp < 8u && (unsigned)dyp < 8u) {
+                            pd.PA |= 1ull << (dyp * 8 + dxp);
+                        } else {
+                            if (pd.PA != 0ull) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                            pd.PA = 1ull; pd.pox = x; pd.poy = y;
+                        }
                     }
-                    if (lane == 0) lsdg_mark(F, x + y * P.W, 1);
+                    if (lane == 0) lsdg_mark<LU>(F, x + y * P.W, 1);
                     continue;
                 }
                 double reg_angle;
                 bool touched = false;
-                int reg_size = lsdg_region_grow4(F, x, y, &reg_angle, P.prec, fcP, pd, false, trip_end, touched);
+                int reg_size = lsdg_region_grow4<LU>(F, x, y, &reg_angle, P.prec, fcP, pd, false, trip_end, touched);
                 if (touched) { stale = true; dirty = true; }
                 if (reg_size < P.min_reg_size) continue;
 #if PSL_GROW_DIAG == 1
@@ -1369,7 +1397,7 @@ __global__ __launch_bounds__(64 * (1 + HELPERS), HELPERS ? 1 : PSL_GROW_WAVES) v
 #if PSL_GROW_DIAG == 2
                 const int kept = reg_size;
 #else
-                const int kept = lsdw_refine(F, reg_size, reg_angle, P.prec, &rec, 0.7, pd, trip_end, touched);
+                const int kept = lsdw_refine<LU>(F, reg_size, reg_angle, P.prec, &rec, 0.7, pd, trip_end, touched);
 #endif
                 if (touched) { stale = true; dirty = true; }
                 if (!kept) continue;

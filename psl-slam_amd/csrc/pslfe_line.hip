@@ -11,6 +11,10 @@
 #include "line_kernels3.h"
 #include "pslfe_internal.h"
 
+#ifndef PSL_GROW_LDS_USED
+#define PSL_GROW_LDS_USED 1                  // launches with helper waves keep the `used` bits in LDS (0: in memory, as the many-frames launches do; A/B)
+#endif
+#define PSL_GROW_LDS_USED_MAX (144u * 1024u)   // of the CU's 160 KB (the kernel's own arrays take 4 KB): scaled images up to ~1.18 M pixels
 #ifndef PSL_GROW_HELPER_FRAMES
 #define PSL_GROW_HELPER_FRAMES 64   // launches of at most this many frames run k_lsd_grow4 with helper waves (measured: tools/helper_sweep.sh)
 #endif
@@ -38,6 +42,7 @@ struct pslfe_line {
     uint32_t* d_reg = nullptr;
     LsdnTables NT = {};           // LSD_REFINE_ADV: log_gamma / log(p) tables of nfa() (NT.lg in HBM)
     double* d_lgamma = nullptr;
+    size_t lds_used_attr = 64u * 1024u;   // dynamic LDS k_lsd_grow4<3, 1> has been allowed so far
     double* d_sctab = nullptr;    // psl_sincostab.inc
     double* d_rects = nullptr;    // LSD_REFINE_ADV: rectangles of k_lsd_grow4 for k_lsd_nfa
     int* d_nrect = nullptr;
@@ -279,10 +284,19 @@ struct pslfe_line {
         {
             PSL_STAGE_BEGIN(ctx, "line.lsd_grow");
             // LSD_REFINE_ADV: the kernel leaves rectangles (d_rects / d_nrect) for the NFA validation below
-            if (F <= PSL_GROW_HELPER_FRAMES)  // few workgroups per XCD: three more waves each keep that XCD's L2 warm in front of the chain (line_kernels.h)
-                k_lsd_grow4<3><<<F, 256, 0, st>>>(P, d_angdeg, d_modgrad, d_trig, d_used, d_seedt, d_reg, d_seg, refine >= 2 ? d_nrect : d_nseg, d_rects, (int)F, nullptr);
-            else
-                k_lsd_grow4<0><<<F, 64, 0, st>>>(P, d_angdeg, d_modgrad, d_trig, d_used, d_seedt, d_reg, d_seg, refine >= 2 ? d_nrect : d_nseg, d_rects, (int)F,
+            if (F <= PSL_GROW_HELPER_FRAMES) {  // few workgroups per XCD: three more waves each keep that XCD's L2 warm in front of the chain (line_kernels.h)
+                const size_t ubytes = (((size_t)P.W * P.H + 31) >> 5) * 4;   // the `used` bits of the frame in LDS (24 KB at 640x480, 96 KB at 1280x960)
+                if (PSL_GROW_LDS_USED && ubytes <= PSL_GROW_LDS_USED_MAX) {
+                    if (ubytes > lds_used_attr) {   // more than the default 64 KB of dynamic LDS needs the attribute (once per size)
+                        PSL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lsd_grow4<3, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ubytes));
+                        lds_used_attr = ubytes;
+                    }
+                    k_lsd_grow4<3, 1><<<F, 256, ubytes, st>>>(P, d_angdeg, d_modgrad, d_trig, d_used, d_seedt, d_reg, d_seg, refine >= 2 ? d_nrect : d_nseg, d_rects, (int)F, nullptr);
+                } else {
+                    k_lsd_grow4<3, 0><<<F, 256, 0, st>>>(P, d_angdeg, d_modgrad, d_trig, d_used, d_seedt, d_reg, d_seg, refine >= 2 ? d_nrect : d_nseg, d_rects, (int)F, nullptr);
+                }
+            } else
+                k_lsd_grow4<0, 0><<<F, 64, 0, st>>>(P, d_angdeg, d_modgrad, d_trig, d_used, d_seedt, d_reg, d_seg, refine >= 2 ? d_nrect : d_nseg, d_rects, (int)F,
                                                  PSL_FRAME_ORDER ? d_order : nullptr);
             PSL_STAGE_END(ctx, "line.lsd_grow");
         }
