@@ -840,6 +840,9 @@ __device__ int lsdg_region_grow4(const LsdW& F, int sx, int sy, double* reg_angl
         const int x = ox + lx, y = oy + ly;
         const bool inside = (unsigned)x < (unsigned)F.W && (unsigned)y < (unsigned)F.H;
         const int cidx = inside ? lsdw_pix(F, x, y) : addr0;
+#ifdef PSL_GROW_STATS
+        const unsigned long long st_l0 = __builtin_amdgcn_s_memtime();
+#endif
         const float2 t = F.trig[cidx];
         const bool ub = lsdg_used<LU>(F, cidx);
         // queue entry -> lane of the window (while the load is in flight)
@@ -852,6 +855,10 @@ __device__ int lsdg_region_grow4(const LsdW& F, int sx, int sy, double* reg_angl
         const int px = x - pox, py = y - poy;
         const bool pa = LU ? false : ((unsigned)px < 8u && (unsigned)py < 8u && ((PA >> (py * 8 + px)) & 1ull) != 0ull);   // (marks in LDS are never "on their way")
         const uint32_t xy = (uint32_t)x | ((uint32_t)y << 16);
+#ifdef PSL_GROW_STATS
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // [8]: cycles from the window's loads to their data (with the LDS map work in their shadow)
+        if (blockIdx.x == 0 && lane == 0) g_gstats[8] += __builtin_amdgcn_s_memtime() - st_l0;
+#endif
         const float cs = t.x, sn = t.y;
         // a lane that holds a queue entry is a pixel of the region (the seed among them: its mark is not in memory yet)
         unsigned long long live = __ballot((int)inside & ((int)(cs != 0.f) | (int)(sn != 0.f)) & (int)!ub & (int)!pa & (int)(seq < 0));   // (no short circuit: one straight run of compares)
@@ -1386,7 +1393,14 @@ __global__ __launch_bounds__(64 * (1 + HELPERS), HELPERS ? 1 : PSL_GROW_WAVES) v
                 }
                 double reg_angle;
                 bool touched = false;
+#ifdef PSL_GROW_STATS
+                const unsigned long long st_g0 = __builtin_amdgcn_s_memtime();
+#endif
                 int reg_size = lsdg_region_grow4<LU>(F, x, y, &reg_angle, P.prec, fcP, pd, false, trip_end, touched);
+#ifdef PSL_GROW_STATS
+                if (frame == 0 && lane == 0) g_gstats[11] += __builtin_amdgcn_s_memtime() - st_g0;
+                const unsigned long long st_r1 = __builtin_amdgcn_s_memtime();
+#endif
                 if (touched) { stale = true; dirty = true; }
                 if (reg_size < P.min_reg_size) continue;
 #if PSL_GROW_DIAG == 1
@@ -1394,10 +1408,17 @@ __global__ __launch_bounds__(64 * (1 + HELPERS), HELPERS ? 1 : PSL_GROW_WAVES) v
 #endif
                 LsdRect rec;
                 lsdw_region2rect(F, reg_size, reg_angle, P.prec, &rec);
+#ifdef PSL_GROW_STATS
+                const unsigned long long st_r2 = __builtin_amdgcn_s_memtime();
+                if (frame == 0 && lane == 0) g_gstats[9] += st_r2 - st_r1;
+#endif
 #if PSL_GROW_DIAG == 2
                 const int kept = reg_size;
 #else
                 const int kept = lsdw_refine<LU>(F, reg_size, reg_angle, P.prec, &rec, 0.7, pd, trip_end, touched);
+#endif
+#ifdef PSL_GROW_STATS
+                if (frame == 0 && lane == 0) g_gstats[10] += __builtin_amdgcn_s_memtime() - st_r2;
 #endif
                 if (touched) { stale = true; dirty = true; }
                 if (!kept) continue;
@@ -1421,6 +1442,8 @@ __global__ __launch_bounds__(64 * (1 + HELPERS), HELPERS ? 1 : PSL_GROW_WAVES) v
         printf("grow clock: %llu shader cycles in %llu ticks of 100 MHz = %.0f MHz\n", dc, dr, (double)dc / (double)dr * 100.0);
         printf("grow stats: regions %llu rounds %llu pops %llu pops_with_candidates %llu decision_blocks %llu exact_tests %llu\n", g_gstats[0], g_gstats[1],
                g_gstats[2], g_gstats[3], g_gstats[4], g_gstats[6]);
+        printf("grow cycles: growth of the scan's regions %llu (of which waiting for the window loads of ALL growths incl. the refinement's %llu), region2rect %llu, refinement %llu\n",
+               g_gstats[11], g_gstats[8], g_gstats[9], g_gstats[10]);
         for (int k = 0; k < 16; ++k) g_gstats[k] = 0;
     }
 #endif
