@@ -434,7 +434,9 @@ __device__ __forceinline__ void lsdn_load(const double* __restrict__ r, LsdnRect
     rec->prec = r[8]; rec->p = r[9];
 }
 
-#define PSL_NFA_GL 16   // lanes per pixel scan: four (rectangle, trial) scans per wave
+#ifndef PSL_NFA_GL
+#define PSL_NFA_GL 16   // lanes per pixel scan: four (rectangle, trial) scans per wave (8: nfa_count 48.7 ms per 12288 dense frames, 16: 39.9, 32: 40.2 - profiles/r03z_ab_nfa_gl.log)
+#endif
 
 template <int PH>
 __global__ __launch_bounds__(256, 4) void k_lsd_nfa_count(LineParams P, const float* __restrict__ angdeg, double* __restrict__ rects,
