@@ -438,8 +438,11 @@ __device__ __forceinline__ void lsdn_load(const double* __restrict__ r, LsdnRect
 #define PSL_NFA_GL 16   // lanes per pixel scan: four (rectangle, trial) scans per wave (8: nfa_count 48.7 ms per 12288 dense frames, 16: 39.9, 32: 40.2 - profiles/r03z_ab_nfa_gl.log)
 #endif
 
+#ifndef PSL_NFA_COUNT_WAVES
+#define PSL_NFA_COUNT_WAVES 8   // register bound: 64 VGPRs (78 at 4): 39.9 -> 38.4 ms per 12288 dense frames (profiles/r03z_ab_nfa_grid.log)
+#endif
 template <int PH>
-__global__ __launch_bounds__(256, 4) void k_lsd_nfa_count(LineParams P, const float* __restrict__ angdeg, double* __restrict__ rects,
+__global__ __launch_bounds__(256, PSL_NFA_COUNT_WAVES) void k_lsd_nfa_count(LineParams P, const float* __restrict__ angdeg, double* __restrict__ rects,
                                                           const int* __restrict__ nrect, const uint8_t* __restrict__ keep, int2* __restrict__ counts) {
     constexpr int TR = 1;                               // scans per rectangle: the five trials of a phase share ONE pass (lsdn_count_trials / lsdn_count<5>)
     constexpr int GPB = 256 / PSL_NFA_GL;               // scans in flight per workgroup

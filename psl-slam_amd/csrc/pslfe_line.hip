@@ -11,6 +11,10 @@
 #include "line_kernels3.h"
 #include "pslfe_internal.h"
 
+#ifndef PSL_NFA_COUNT_WGS
+#define PSL_NFA_COUNT_WGS 4   // workgroups (16 scan groups each) per frame of a many-frames k_lsd_nfa_count launch: 12288 dense frames, 8 waves per SIMD: 1: 38.2 ms, 2: 37.3, 3: 36.9,
+                              // 4: 36.7; at 4 waves per SIMD 4: 38.1, 8: 39.9 (the default until round 3), 16: 45.2, 32: 59.1 (profiles/r03z_ab_nfa_grid.log)
+#endif
 #ifndef PSL_GROW_LDS_USED
 #define PSL_GROW_LDS_USED 1                  // launches with helper waves keep the `used` bits in LDS (0: in memory, as the many-frames launches do; A/B)
 #endif
@@ -305,7 +309,7 @@ struct pslfe_line {
             // set-up, then the binomial tails drawn from a shared counter) and a selection launch (thread = rectangle), line_kernels3.h.  A few hundred rectangles per frame: a many-frames launch fills
             // the chip by frames, a single frame by chunks.  (The stage timers record the launches of a phase as they are issued;
             // with profiling on, every stage costs two event records.)
-            const dim3 gc(F >= 64 ? 8 : 128, F), gs(F >= 64 ? 1 : 4, F);
+            const dim3 gc(F >= 64 ? PSL_NFA_COUNT_WGS : 128, F), gs(F >= 64 ? 1 : 4, F);
 #define PSL_NFA_PHASE(PH)                                                                                                \
     {                                                                                                                    \
         PSL_STAGE_BEGIN(ctx, "line.nfa_count");                                                                          \
