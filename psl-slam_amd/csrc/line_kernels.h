@@ -246,7 +246,10 @@ __device__ __forceinline__ bool lsdg_aligned(double ad, double theta, double pre
 // (thread = 4 pixels of a column): gradient and squared magnitude, the threshold, NOTDEF angles, the flag tile, and the defined
 // pixels appended to an LDS list (any order: every output is a per-pixel store).  Phase B (thread = list entry): magnitude, angle,
 // records.  Phase C: the neighbour records of the pixels that have a defined pixel in their 3 x 3.
-__global__ __launch_bounds__(256) void k_lsd_grad(LineParams P, const double* __restrict__ scaled, float* __restrict__ angdeg,
+#ifndef PSL_GRAD_WAVES
+#define PSL_GRAD_WAVES 1
+#endif
+__global__ __launch_bounds__(256, PSL_GRAD_WAVES) void k_lsd_grad(LineParams P, const double* __restrict__ scaled, float* __restrict__ angdeg,
                                                    double* __restrict__ modgrad, float2* __restrict__ trig, float2* __restrict__ seedt, uint8_t* __restrict__ used,
                                                    int* __restrict__ weight, int nframes, int xcd) {
     __shared__ uint8_t s_def[PSL_GRAD_TH + 2][68];

@@ -701,7 +701,10 @@ __constant__ int c_lbd_combos[32][2] = {{0, 1}, {0, 2}, {0, 3}, {0, 4}, {0, 5}, 
                                         {2, 3}, {2, 4}, {2, 5}, {2, 6}, {2, 7}, {2, 8}, {3, 4}, {3, 5}, {3, 6}, {3, 7}, {3, 8},
                                         {4, 5}, {4, 6}, {4, 7}, {4, 8}, {5, 6}, {5, 7}, {5, 8}, {6, 7}, {6, 8}, {7, 8}};
 
-__global__ __launch_bounds__(256) void k_lbd(LineParams P, const short2* __restrict__ dxyI,
+#ifndef PSL_LBD_WAVES
+#define PSL_LBD_WAVES 1
+#endif
+__global__ __launch_bounds__(256, PSL_LBD_WAVES) void k_lbd(LineParams P, const short2* __restrict__ dxyI,
                                               const PslKeyLine* __restrict__ kls, const int* __restrict__ nkl, uint8_t* __restrict__ desc,
                                               float* __restrict__ fdesc) {
     __shared__ float s_row[4][63][8];
@@ -866,7 +869,11 @@ __device__ __forceinline__ int psl_block_excl_scan256(int v, int* s_w, int* tota
     return inc - v + base;
 }
 
-__global__ __launch_bounds__(256) void k_lil_pair(const float* __restrict__ lines, size_t lstride, int lp, const int* __restrict__ nlines, int nlines_single,
+#ifndef PSL_PAIR_WAVES
+#define PSL_PAIR_WAVES 8   // 56 VGPRs instead of 58: 8 waves per SIMD instead of 7, 4.88 -> 4.37 ms per 12288 dense frames (profiles/r03z_ab_waves_misc.log; the same knob
+                         // does nothing for k_lsd_grad and costs k_lbd and k_line_good their registers: left as they are)
+#endif
+__global__ __launch_bounds__(256, PSL_PAIR_WAVES) void k_lil_pair(const float* __restrict__ lines, size_t lstride, int lp, const int* __restrict__ nlines, int nlines_single,
                                                    float radius, float fanThr, int imgCols, int imgRows, float* __restrict__ raw,
                                                    float* __restrict__ fans, int fan_cap, int* __restrict__ nfans) {
     __shared__ int s_w[4];
