@@ -535,7 +535,9 @@ __global__ __launch_bounds__(256, PSL_NFA_COUNT_WAVES) void k_lsd_nfa_count(Line
 struct LsdnSeries { double term, p_term; int n, i; float stop; uint16_t slot, pad; };
 static_assert(sizeof(LsdnSeries) == 32, "LsdnSeries is 32 bytes");
 #define PSL_NFA_NCLS 12   // length classes of the series: class c holds predicted lengths in [2^c, 2^(c+1)) (c = 11: all longer ones)
-#define PSL_NFA_FG 16     // frames whose series of one class are summed by one workgroup
+#ifndef PSL_NFA_FG
+#define PSL_NFA_FG 16     // frames whose series of one class are summed by one workgroup (8: nfa_eval 29.0 ms per 12288 dense frames, 16: 27.3, 32: 42.6, 64: 50.2 - profiles/r03z_ab_nfa_fg.log)
+#endif
 
 // predicted number of terms of the tail of B(n, p) from k + 1: the climb to the mode n p (if k is below it) plus a few standard
 // deviations, never more than n - k.  Only a scheduling hint: series of similar predicted length share a wave.
