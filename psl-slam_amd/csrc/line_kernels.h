@@ -382,7 +382,9 @@ __global__ __launch_bounds__(256, PSL_GRAD_WAVES) void k_lsd_grad(LineParams P, 
 // (longest processing time first) the tail is made of the lightest frames.  weight = number of pixels with a defined gradient,
 // counted by k_lsd_grad (one atomic per tile); the order is a counting sort over 1024 weight classes by one workgroup (the order
 // inside a class is whatever the atomics give: it only affects the schedule, never a result).
+#ifndef PSL_LSD_SUBBATCH
 #define PSL_LSD_SUBBATCH 2048   // frames whose f64 working image is resident between k_lsd_scale_tiled and k_lsd_grad (pslfe_line.hip: run_lsd)
+#endif
 #ifndef PSL_FRAME_ORDER
 #define PSL_FRAME_ORDER 1   // 0: frames in index order (A/B, tools/ab_build.sh)
 #endif

@@ -152,6 +152,18 @@ def test_lsd_reduce_region_radius_on_a_queue_of_most_of_the_image():
     assert over == len(cases) and steps > 100, (over, steps)
 
 
+@pytest.mark.parametrize("w,h", [(1536, 1152), (1600, 1200)])
+def test_lsd_one_large_frame_on_both_sides_of_the_lds_map_limit(w, h):
+    """A few-frames launch keeps the `used` bits of the scaled image in LDS when they fit beside the kernel's own arrays (144 KB: ~1.18 M pixels):
+    1536x1152 scales to 1228x921 = 138 KB of bits (k_lsd_grow4<3, 1> with nearly all of the CU's LDS as dynamic shared memory), 1600x1200 to
+    1280x960 = 150 KB (the map stays in memory: k_lsd_grow4<3, 0>).  Segments bit for bit on either side."""
+    import oracle_lib
+    img = _scene("struct", 23, 1, w, h)
+    ref = oracle_lib.lsd_detect(img)
+    got = _extractor(ADV).lsd_detect(img)
+    assert len(ref) > 100 and got.shape == ref.shape and (got.view(np.uint32) == ref.view(np.uint32)).all()
+
+
 def _adversarial_images():
     """Inputs that stress the queue order of the region growing rather than look like a room: rings (regions that turn and close on
     themselves), stripes of every thickness in both diagonals (frontiers several entries wide, growth up and to the left of the seed),
