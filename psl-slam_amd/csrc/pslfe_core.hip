@@ -42,6 +42,16 @@ int pslfe_ctx::resolve_pending() {
     return PSLFE_OK;
 }
 
+char* psl_host_stage(pslfe_ctx* ctx, size_t bytes) {
+    if (bytes <= ctx->hstage_cap) return ctx->hstage;
+    if (ctx->hstage) { hipHostFree(ctx->hstage); ctx->hstage = nullptr; ctx->hstage_cap = 0; }
+    const size_t want = psl_align_up(bytes + bytes / 2, (size_t)1 << 16);
+    void* q = nullptr;
+    if (hipHostMalloc(&q, want, hipHostMallocDefault) != hipSuccess) return nullptr;
+    ctx->hstage = static_cast<char*>(q); ctx->hstage_cap = want;
+    return ctx->hstage;
+}
+
 int psl_scratch_begin(pslfe_ctx* ctx) {
     if (!ctx->arena_extra.empty()) {   // the previous call outgrew the arena: its fall-back blocks go, and the arena grows
         PSL_HIP(hipStreamSynchronize(ctx->stream));
@@ -129,6 +139,7 @@ void pslfe_ctx_destroy(pslfe_ctx* ctx) {
     hipStreamSynchronize(ctx->stream);
     for (void* q : ctx->arena_extra) hipFree(q);
     if (ctx->arena) hipFree(ctx->arena);
+    if (ctx->hstage) hipHostFree(ctx->hstage);
     if (ctx->aux_stream) hipStreamSynchronize(ctx->aux_stream);
     ctx->resolve_pending();
     if (ctx->ev_fork) hipEventDestroy(ctx->ev_fork);

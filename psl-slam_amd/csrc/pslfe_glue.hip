@@ -817,27 +817,39 @@ int pslfe_glue_fetch(pslfe_glue* g, int frame, int nlines, double* lines3d, floa
     PSL_HIP(hipSetDevice(g->ctx->device));
     hipStream_t st = g->ctx->stream;
     const size_t f = (size_t)frame;
-    int ni = 0, np = 0;
-    PSL_HIP(hipMemcpyAsync(&ni, g->d_nint + f, sizeof(int), hipMemcpyDeviceToHost, st));
-    PSL_HIP(hipMemcpyAsync(&np, g->d_nplanes + f, sizeof(int), hipMemcpyDeviceToHost, st));
+    // counts first (8 bytes through the pinned staging buffer), then every slice into the staging buffer in one go, one wait, host copies
+    const size_t L = (size_t)g->max_lines, I = (size_t)g->int_cap, Pn = (size_t)g->plane_cap;
+    char* hs = psl_host_stage(g->ctx, 64);
+    PSL_REQUIRE(hs, PSLFE_E_HIP, "pslfe_glue_fetch: no pinned staging memory (hipHostMalloc)");
+    PSL_HIP(hipMemcpyAsync(hs, g->d_nint + f, sizeof(int), hipMemcpyDeviceToHost, st));
+    PSL_HIP(hipMemcpyAsync(hs + 4, g->d_nplanes + f, sizeof(int), hipMemcpyDeviceToHost, st));
     PSL_HIP(hipStreamSynchronize(st));
+    int ni = 0, np = 0;
+    memcpy(&ni, hs, 4); memcpy(&np, hs + 4, 4);
     *nint = ni; *nplanes = np;
     PSL_REQUIRE(ni <= g->int_cap && np <= g->plane_cap, PSLFE_E_CAPACITY, "pslfe_glue_fetch: %d crossings / %d planes exceed the handle's capacity %d", ni, np, g->int_cap);
     PSL_REQUIRE(ni <= int_cap && np <= plane_cap, PSLFE_E_CAPACITY, "pslfe_glue_fetch: %d crossings / %d planes, capacities %d / %d", ni, np, int_cap, plane_cap);
-    auto D = [&](void* dst, const void* src, size_t bytes) -> hipError_t { return (dst && bytes) ? hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, st) : hipSuccess; };
-    const size_t L = (size_t)g->max_lines, I = (size_t)g->int_cap, Pn = (size_t)g->plane_cap;
-    PSL_HIP(D(lines3d, g->d_lines3d + f * L * 6, (size_t)nlines * 6 * sizeof(double)));
-    PSL_HIP(D(lineEq, g->d_lineEq + f * L * 3, (size_t)nlines * 3 * sizeof(float)));
-    PSL_HIP(D(pair, g->d_pair + f * I * 2, (size_t)ni * 2 * sizeof(int32_t)));
-    PSL_HIP(D(xy, g->d_xy + f * I * 2, (size_t)ni * 2 * sizeof(float)));
-    PSL_HIP(D(cross, g->d_cross + f * I * 3, (size_t)ni * 3 * sizeof(double)));
-    PSL_HIP(D(le_l, g->d_le_l + f * I * 6, (size_t)ni * 6 * sizeof(double)));
-    PSL_HIP(D(planes, g->d_planes + f * Pn * 4, (size_t)np * 4 * sizeof(float)));
-    PSL_HIP(D(normals, g->d_normals + f * Pn * 3, (size_t)np * 3 * sizeof(double)));
-    PSL_HIP(D(lineNo, g->d_lineNo + f * Pn * 2, (size_t)np * 2 * sizeof(int32_t)));
-    PSL_HIP(D(cross3d, g->d_cross3d + f * Pn * 3, (size_t)np * 3 * sizeof(double)));
-    PSL_HIP(D(cross2d, g->d_cross2d + f * Pn * 2, (size_t)np * 2 * sizeof(double)));
-    PSL_HIP(hipStreamSynchronize(st));
+    struct Piece { void* dst; const void* src; size_t bytes; };
+    const Piece pc[11] = {
+        {lines3d, g->d_lines3d + f * L * 6, (size_t)nlines * 6 * sizeof(double)}, {lineEq, g->d_lineEq + f * L * 3, (size_t)nlines * 3 * sizeof(float)},
+        {pair, g->d_pair + f * I * 2, (size_t)ni * 2 * sizeof(int32_t)},           {xy, g->d_xy + f * I * 2, (size_t)ni * 2 * sizeof(float)},
+        {cross, g->d_cross + f * I * 3, (size_t)ni * 3 * sizeof(double)},          {le_l, g->d_le_l + f * I * 6, (size_t)ni * 6 * sizeof(double)},
+        {planes, g->d_planes + f * Pn * 4, (size_t)np * 4 * sizeof(float)},        {normals, g->d_normals + f * Pn * 3, (size_t)np * 3 * sizeof(double)},
+        {lineNo, g->d_lineNo + f * Pn * 2, (size_t)np * 2 * sizeof(int32_t)},      {cross3d, g->d_cross3d + f * Pn * 3, (size_t)np * 3 * sizeof(double)},
+        {cross2d, g->d_cross2d + f * Pn * 2, (size_t)np * 2 * sizeof(double)}};
+    size_t total = 0;
+    for (const Piece& q : pc) if (q.dst && q.bytes) total += psl_align_up(q.bytes, 16);
+    if (total) {
+        hs = psl_host_stage(g->ctx, total);
+        PSL_REQUIRE(hs, PSLFE_E_HIP, "pslfe_glue_fetch: no pinned staging memory (hipHostMalloc)");
+        size_t o = 0;
+        for (const Piece& q : pc)
+            if (q.dst && q.bytes) { PSL_HIP(hipMemcpyAsync(hs + o, q.src, q.bytes, hipMemcpyDeviceToHost, st)); o += psl_align_up(q.bytes, 16); }
+        PSL_HIP(hipStreamSynchronize(st));
+        o = 0;
+        for (const Piece& q : pc)
+            if (q.dst && q.bytes) { memcpy(q.dst, hs + o, q.bytes); o += psl_align_up(q.bytes, 16); }
+    }
     return PSLFE_OK;
 }
 

@@ -56,6 +56,10 @@ struct pslfe_ctx {
     char* arena = nullptr;
     size_t arena_cap = 0, arena_used = 0, arena_want = 0;
     std::vector<void*> arena_extra;
+    // Pinned host staging of the per-frame fetch functions (pslfe_glue_fetch, pslfe_frame_fetch): a device-to-host copy into the caller's pageable
+    // vectors blocks for ~20 us each, and a fetch is up to 13 of them; into pinned memory they are queued in ~2 us each and waited for once.
+    char* hstage = nullptr;
+    size_t hstage_cap = 0;
 
     int stage_begin(const char* name, hipEvent_t* a, hipEvent_t* b, hipStream_t on = nullptr);
     int stage_end(const char* name, hipEvent_t a, hipEvent_t b, hipStream_t on = nullptr);
@@ -92,6 +96,8 @@ struct pslfe_ctx {
 
 static inline size_t psl_align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// at least `bytes` of pinned host memory owned by the context (valid until the next call that asks for more); nullptr on failure
+char* psl_host_stage(pslfe_ctx* ctx, size_t bytes);
 // start of a call: releases the previous call's fall-back blocks and grows the arena to what that call wanted (calls on a context are serialised)
 int psl_scratch_begin(pslfe_ctx* ctx);
 // `bytes` of device memory valid until the next psl_scratch_begin on this context (256-byte aligned); nullptr on failure

@@ -801,17 +801,27 @@ int pslfe_frame_fetch(pslfe_frame* f, int slot, PslKeyPoint* kps_un, float* dept
     PSL_REQUIRE(slot >= 0 && slot < f->max_frames && f->slot_set[slot], PSLFE_E_STATE, "pslfe_frame_fetch: slot %d not set", slot);
     PSL_HIP(hipSetDevice(f->ctx->device));
     hipStream_t st = f->ctx->stream;
+    // through the context's pinned staging buffer (pslfe_internal.h): the slot's meta record, then the three arrays with one wait
     FrameMeta m;
-    PSL_HIP(hipMemcpyAsync(&m, f->S.meta + slot, sizeof(m), hipMemcpyDeviceToHost, st));
+    char* hs = psl_host_stage(f->ctx, sizeof(m));
+    PSL_REQUIRE(hs, PSLFE_E_HIP, "pslfe_frame_fetch: no pinned staging memory (hipHostMalloc)");
+    PSL_HIP(hipMemcpyAsync(hs, f->S.meta + slot, sizeof(m), hipMemcpyDeviceToHost, st));
     PSL_HIP(hipStreamSynchronize(st));
+    memcpy(&m, hs, sizeof(m));
     *n = m.n;
     PSL_REQUIRE(m.n <= cap, PSLFE_E_CAPACITY, "pslfe_frame_fetch: %d keypoints, capacity %d", m.n, cap);
     const size_t o = (size_t)slot * f->cap;
     if (m.n > 0) {
-        if (kps_un) PSL_HIP(hipMemcpyAsync(kps_un, f->S.kps + o, (size_t)m.n * sizeof(PslKeyPoint), hipMemcpyDeviceToHost, st));
-        if (depth) PSL_HIP(hipMemcpyAsync(depth, f->d_depth + o, (size_t)m.n * sizeof(float), hipMemcpyDeviceToHost, st));
-        if (uright) PSL_HIP(hipMemcpyAsync(uright, f->S.uright + o, (size_t)m.n * sizeof(float), hipMemcpyDeviceToHost, st));
+        const size_t bk = psl_align_up((size_t)m.n * sizeof(PslKeyPoint), 16), bf = psl_align_up((size_t)m.n * sizeof(float), 16);
+        hs = psl_host_stage(f->ctx, bk + 2 * bf);
+        PSL_REQUIRE(hs, PSLFE_E_HIP, "pslfe_frame_fetch: no pinned staging memory (hipHostMalloc)");
+        if (kps_un) PSL_HIP(hipMemcpyAsync(hs, f->S.kps + o, (size_t)m.n * sizeof(PslKeyPoint), hipMemcpyDeviceToHost, st));
+        if (depth) PSL_HIP(hipMemcpyAsync(hs + bk, f->d_depth + o, (size_t)m.n * sizeof(float), hipMemcpyDeviceToHost, st));
+        if (uright) PSL_HIP(hipMemcpyAsync(hs + bk + bf, f->S.uright + o, (size_t)m.n * sizeof(float), hipMemcpyDeviceToHost, st));
         PSL_HIP(hipStreamSynchronize(st));
+        if (kps_un) memcpy(kps_un, hs, (size_t)m.n * sizeof(PslKeyPoint));
+        if (depth) memcpy(depth, hs + bk, (size_t)m.n * sizeof(float));
+        if (uright) memcpy(uright, hs + bk + bf, (size_t)m.n * sizeof(float));
     }
     return PSLFE_OK;
 }
