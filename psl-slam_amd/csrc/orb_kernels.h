@@ -226,6 +226,9 @@ __global__ __launch_bounds__(256) void k_pyr_resize_tiled(OrbParams P, FrameSrc 
 //     test scores below minTh - and both only for the rare pixel where both pass;
 //   * NMS and the raster-ordered output are driven by the compacted list (a few % of the pixels): survivors
 //     set a bit in a per-row mask, row prefix sums give the raster positions.
+#ifndef PSL_FAST_DIAG
+#define PSL_FAST_DIAG 0   // timing builds only (tools/ab_round3x.sh): 1 = the quick test twice, 2 = the scores twice, 3 = NMS + output twice, 4 = tile load + clears twice (same results)
+#endif
 #define PSL_FAST4_TP 76   // tile pitch (bytes): 1 + (64 + 6) + slack, multiple of 4
 #define PSL_FAST4_SP 72   // score pitch (bytes): interior x at byte 4 + x
 __device__ __forceinline__ uint32_t psl_alignbyte(uint32_t hi, uint32_t lo, uint32_t sh) { return __builtin_amdgcn_alignbyte(hi, lo, sh); }
@@ -246,6 +249,40 @@ __device__ __forceinline__ int psl_fast_score_pol(const uint8_t* c, const int tp
     int A = -256;
 #pragma unroll
     for (int k = 0; k < 16; ++k) A = max(A, min(min(lo4[k], lo4[(k + 4) & 15]), e[(k + 8) & 15]));
+    return A - 1;
+}
+
+#ifndef PSL_FAST_SCORE_PK
+#define PSL_FAST_SCORE_PK 1   // 0: psl_fast_score_pol, one ring difference per instruction (A/B, tools/ab_build.sh)
+#endif
+// The same score with TWO ring positions per instruction (packed signed 16-bit: the differences lie in [-255, 255]).  The scores are 36 % of the kernel
+// (12.9 of 35.4 ms per 12288 dense frames, profiles/r03g_fast_parts_twice.log) and the kernel is bound by vector issue.  E[j] = (e[2j], e[2j+1]),
+// O[j] = (e[2j+1], e[2j+2]) (one v_alignbit of two E's); then min over a pair of neighbours, over four, over the nine of an arc, and the maximum
+// over the arcs, all on pairs: 41 packed instructions instead of 80, and e = sgn v - sgn ring is one packed multiply-add per pair.
+// Measured: 35.15 -> 34.63 ms (profiles/r03g_ab_fast_score_pk.log) - far less than the instruction count promised: the 16 byte reads of the ring from LDS, not the
+// min / max tree, are what a score costs.
+typedef short psl_i16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ int psl_fast_score_pol_pk(const uint8_t* c, const int tp, const int sgn) {
+    const uint32_t r[16] = {c[3 * tp],  c[3 * tp + 1],  c[2 * tp + 2],  c[tp + 3],  c[3],  c[-tp + 3], c[-2 * tp + 2], c[-3 * tp + 1],
+                            c[-3 * tp], c[-3 * tp - 1], c[-2 * tp - 2], c[-tp - 3], c[-3], c[tp - 3],  c[2 * tp - 2],  c[3 * tp - 1]};
+    const short sv = (short)(sgn * (int)c[0]), ns = (short)-sgn;
+    const psl_i16x2 SV = {sv, sv}, NS = {ns, ns};
+    psl_i16x2 E[8], O[8], L2[8], L4[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) E[j] = __builtin_bit_cast(psl_i16x2, r[2 * j] | (r[2 * j + 1] << 16)) * NS + SV;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+        O[j] = __builtin_bit_cast(psl_i16x2, __builtin_amdgcn_alignbit(__builtin_bit_cast(uint32_t, E[(j + 1) & 7]), __builtin_bit_cast(uint32_t, E[j]), 16u));
+#pragma unroll
+    for (int j = 0; j < 8; ++j) L2[j] = __builtin_elementwise_min(E[j], O[j]);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) L4[j] = __builtin_elementwise_min(L2[j], L2[(j + 1) & 7]);
+    psl_i16x2 T[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) T[j] = __builtin_elementwise_min(__builtin_elementwise_min(L4[j], L4[(j + 2) & 7]), E[(j + 4) & 7]);
+    const psl_i16x2 a = __builtin_elementwise_max(__builtin_elementwise_max(__builtin_elementwise_max(T[0], T[1]), __builtin_elementwise_max(T[2], T[3])),
+                                                  __builtin_elementwise_max(__builtin_elementwise_max(T[4], T[5]), __builtin_elementwise_max(T[6], T[7])));
+    const int A = a.x > a.y ? (int)a.x : (int)a.y;
     return A - 1;
 }
 
@@ -286,6 +323,10 @@ __global__ __launch_bounds__(256, 8) void k_fast_cells4(OrbParams P, FrameSrc S,
     // LDS tile byte (1 + x) of row y = image pixel (iniX + x, iniY + y); dword d of a row = image bytes
     // iniX - 1 + 4d .. + 3, assembled from the two aligned global dwords that hold them
     const bool aligned4 = ((reinterpret_cast<uintptr_t>(img) | (uintptr_t)pitch) & 3) == 0 && iniX >= 4 && maxX + 8 <= pitch;
+#if PSL_FAST_DIAG == 4
+  for (int diag_rep = 0; diag_rep < 2; ++diag_rep) {
+    asm volatile("" ::: "memory");
+#endif
     const int ndw = (tw + 4) >> 2;  // <= 18
     if (aligned4) {
         const int gx0 = (iniX - 1) & ~3;
@@ -306,6 +347,9 @@ __global__ __launch_bounds__(256, 8) void k_fast_cells4(OrbParams P, FrameSrc S,
     (&s_rowmask[0][0][0])[tid] = 0;  // 2 * 64 * 2 words
     if (tid == 0) s_nlist = 0;
     __syncthreads();
+#if PSL_FAST_DIAG == 4
+  }
+#endif
 
     const int ng = (iw + 3) >> 2;            // groups of 4 pixels per row, <= 16
     const int nitems = ng * ih;              // <= 1024
@@ -320,6 +364,10 @@ __global__ __launch_bounds__(256, 8) void k_fast_cells4(OrbParams P, FrameSrc S,
         const int idx = p * 256 + tid;
         uint32_t m4 = 0, pol = 0;  // pol: 2 bits per pixel
         int y = 0, g = 0;
+#if PSL_FAST_DIAG == 1
+      for (int diag_rep = 0; diag_rep < 2; ++diag_rep) {
+        asm volatile("" ::: "memory");
+#endif
         if (idx < nitems) {
             y = (int)(((uint32_t)idx * magic) >> 20);
             g = idx - y * ng;
@@ -361,6 +409,10 @@ __global__ __launch_bounds__(256, 8) void k_fast_cells4(OrbParams P, FrameSrc S,
             if (nin < 4) pol &= (1u << (2 * nin)) - 1u;
             m4 = ((pol | (pol >> 1)) & 0x1u) | (((pol | (pol >> 1)) >> 1) & 0x2u) | (((pol | (pol >> 1)) >> 2) & 0x4u) | (((pol | (pol >> 1)) >> 3) & 0x8u);
         }
+#if PSL_FAST_DIAG == 1
+        asm volatile("" : "+v"(m4), "+v"(pol));
+      }
+#endif
         // order inside s_list is irrelevant: one slot range per (wave, jj)
         const unsigned long long b0 = __ballot(m4 & 1), b1 = __ballot(m4 & 2), b2 = __ballot(m4 & 4), b3 = __ballot(m4 & 8);
         const int n0 = __popcll(b0), n1 = __popcll(b1), n2 = __popcll(b2), n3 = __popcll(b3);
@@ -378,17 +430,34 @@ __global__ __launch_bounds__(256, 8) void k_fast_cells4(OrbParams P, FrameSrc S,
     }
     __syncthreads();
     const int nlist = s_nlist;
+#if PSL_FAST_DIAG == 2
+  for (int diag_rep = 0; diag_rep < 2; ++diag_rep) {
+    asm volatile("" ::: "memory");
+#endif
     for (int k = tid; k < nlist; k += 256) {
         const int e = s_list[k];
         const int y = (e >> 6) & 63, x = e & 63, pl = e >> 12;
         const uint8_t* c = &s_tile[(y + 3) * PSL_FAST4_TP + x + 4];
         // polarity bit 0: ring brighter than the centre (ring - v), bit 1: ring darker (v - ring)
+#if PSL_FAST_SCORE_PK
+        int s = psl_fast_score_pol_pk(c, PSL_FAST4_TP, (pl & 1) ? -1 : 1);
+        if (pl == 3) s = max(s, psl_fast_score_pol_pk(c, PSL_FAST4_TP, 1));
+#else
         int s = psl_fast_score_pol(c, PSL_FAST4_TP, (pl & 1) ? -1 : 1);
         if (pl == 3) s = max(s, psl_fast_score_pol(c, PSL_FAST4_TP, 1));
+#endif
         s = s < minTh ? 0 : (s > 255 ? 255 : s);
         s_score[(y + 1) * PSL_FAST4_SP + x + 4] = (uint8_t)s;
     }
+#if PSL_FAST_DIAG == 2
+  }
+#endif
     __syncthreads();
+#if PSL_FAST_DIAG == 3
+  for (int diag_rep = 0; diag_rep < 2; ++diag_rep) {
+    asm volatile("" ::: "memory");
+    __syncthreads();
+#endif
     // cv::FAST's NMS: strictly greater than the 8 neighbours (scores outside the interior are 0)
     for (int k = tid; k < nlist; k += 256) {
         const int e = s_list[k];
@@ -434,7 +503,13 @@ __global__ __launch_bounds__(256, 8) void k_fast_cells4(OrbParams P, FrameSrc S,
                 out[pos] = (uint32_t)(x + 3 + j * L.wCell) | ((uint32_t)(y + 3 + i * L.hCell) << 12) | (sc << 24);
         }
     }
+#if PSL_FAST_DIAG == 3
+    if (diag_rep == 1)
+#endif
     if (tid == 0) *out_cnt = total < P.cellcap ? total : P.cellcap;
+#if PSL_FAST_DIAG == 3
+  }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------

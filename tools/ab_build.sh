@@ -9,6 +9,6 @@ for f in "$@"; do
   timeout -k 10 400 python bench.py $args 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
-print(round(d['value']), d['ms_per_step'], {k: round(v, 2) for k, v in d.get('stages_ms_per_step', {}).items() if k in ('line.lsd_scale', 'line.lsd_grad', 'line.lsd_grow')})" || exit 1
+print(round(d['value']), d['ms_per_step'], {k: round(v, 2) for k, v in d.get('stages_ms_per_step', {}).items() if k in ('orb.fast', 'orb.blur', 'orb.describe')})" || exit 1
 done
 done
